@@ -1,0 +1,658 @@
+"""ctypes binding of the CPU parity oracle (oracle/librt_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by the cpu_baseline leg of bench.py,
+as the checker.  Nothing under raytracer_rs_amd/ imports this module.
+
+The TOML reading here uses `tomli`, independent of the product's own C++ TOML-subset parser, so that scene
+loading is checked by two unrelated parsers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+import threading
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librt_oracle.so")
+
+SPHERE, PLANE, CUBE, CYLINDER, CONE, GROUP = range(6)
+KIND_BY_NAME = {"sphere": SPHERE, "plane": PLANE, "cube": CUBE, "cylinder": CYLINDER, "cone": CONE, "group": GROUP}
+PAT_NONE, PAT_STRIPE, PAT_GRADIENT, PAT_RING, PAT_CHECKERS, PAT_TEST = -1, 0, 1, 2, 3, 4
+PATTERN_BY_NAME = {"stripe": PAT_STRIPE, "gradient": PAT_GRADIENT, "ring": PAT_RING, "checkers": PAT_CHECKERS}
+
+
+class Mat4(C.Structure):
+    _fields_ = [("m", (C.c_double * 4) * 4)]
+
+    @staticmethod
+    def from_rows(rows) -> "Mat4":
+        m = Mat4()
+        for i in range(4):
+            for j in range(4):
+                m.m[i][j] = float(rows[i][j])
+        return m
+
+    def rows(self) -> List[List[float]]:
+        return [[self.m[i][j] for j in range(4)] for i in range(4)]
+
+    def numpy(self) -> np.ndarray:
+        return np.array(self.rows(), dtype=np.float64)
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+    def tuple(self):
+        return (self.x, self.y, self.z)
+
+
+class Ray(C.Structure):
+    _fields_ = [("origin", Vec3), ("direction", Vec3)]
+
+
+class Color(C.Structure):
+    _fields_ = [("r", C.c_double), ("g", C.c_double), ("b", C.c_double)]
+
+    def tuple(self):
+        return (self.r, self.g, self.b)
+
+
+class Bounds(C.Structure):
+    _fields_ = [("min", Vec3), ("max", Vec3)]
+
+
+class Pattern(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("transform", Mat4), ("a", Color), ("b", Color)]
+
+
+class Material(C.Structure):
+    _fields_ = [("color", Color), ("ambient", C.c_double), ("diffuse", C.c_double), ("specular", C.c_double),
+                ("shininess", C.c_double), ("reflectivity", C.c_double), ("transparency", C.c_double),
+                ("refractive_index", C.c_double), ("pattern", Pattern)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("hsize", C.c_uint32), ("vsize", C.c_uint32), ("field_of_view", C.c_double), ("transform", Mat4),
+                ("pixel_size", C.c_double), ("half_width", C.c_double), ("half_height", C.c_double)]
+
+
+class Comps(C.Structure):
+    _fields_ = [("time", C.c_double), ("object", C.c_int32), ("inside", C.c_int32), ("point", Vec3),
+                ("eye_vector", Vec3), ("normal_vector", Vec3), ("reflect_vector", Vec3), ("over_point", Vec3),
+                ("under_point", Vec3), ("n1", C.c_double), ("n2", C.c_double)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("primary", C.c_uint64), ("shadow", C.c_uint64), ("reflect", C.c_uint64),
+                ("refract", C.c_uint64), ("prim_tests", C.c_uint64 * 5), ("prim_hits", C.c_uint64 * 5),
+                ("aabb_tests", C.c_uint64), ("ray_transforms", C.c_uint64), ("shades", C.c_uint64),
+                ("lit", C.c_uint64), ("specular", C.c_uint64), ("patterns", C.c_uint64),
+                ("refract_setups", C.c_uint64), ("schlick", C.c_uint64)]
+
+    def as_dict(self) -> dict:
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if hasattr(v, "__len__") else int(v)
+        return d
+
+    def add(self, other: "Counters") -> None:
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            if hasattr(v, "__len__"):
+                o = getattr(other, name)
+                for i in range(len(v)):
+                    v[i] += o[i]
+            else:
+                setattr(self, name, v + getattr(other, name))
+
+
+class TransformCfg(C.Structure):
+    _fields_ = [("has_translate", C.c_int32), ("has_scale", C.c_int32), ("has_rotate_x", C.c_int32),
+                ("has_rotate_y", C.c_int32), ("has_rotate_z", C.c_int32), ("_pad", C.c_int32),
+                ("translate", C.c_double * 3), ("scale", C.c_double * 3), ("rotate_x", C.c_double),
+                ("rotate_y", C.c_double), ("rotate_z", C.c_double)]
+
+
+class MaterialCfg(C.Structure):
+    _fields_ = [("color", C.c_double * 3), ("ambient", C.c_double), ("diffuse", C.c_double),
+                ("specular", C.c_double), ("shininess", C.c_double), ("reflectivity", C.c_double),
+                ("transparency", C.c_double), ("refractive_index", C.c_double), ("pattern_kind", C.c_int32),
+                ("_pad", C.c_int32), ("color_a", C.c_double * 3), ("color_b", C.c_double * 3),
+                ("pattern_transform", TransformCfg)]
+
+
+class ObjectCfg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_children", C.c_int32), ("has_transform", C.c_int32),
+                ("has_material", C.c_int32), ("has_minimum", C.c_int32), ("has_maximum", C.c_int32),
+                ("has_closed", C.c_int32), ("closed", C.c_int32), ("minimum", C.c_double), ("maximum", C.c_double),
+                ("transform", TransformCfg), ("material", MaterialCfg)]
+
+
+class CameraCfg(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("fov", C.c_double), ("from_", C.c_double * 3),
+                ("to", C.c_double * 3), ("up", C.c_double * 3)]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def build(force: bool = False) -> str:
+    """Compiles oracle/librt_oracle.so with the committed Makefile (gcc, -ffp-contract=off)."""
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(
+            os.path.join(_HERE, "rt_oracle.c")):
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                build()
+            L = C.CDLL(_LIB_PATH)
+            _declare(L)
+            _lib = L
+    return _lib
+
+
+def _declare(L: C.CDLL) -> None:
+    P = C.POINTER
+    dbl, i32, vp = C.c_double, C.c_int, C.c_void_p
+    sig = {
+        "orc_last_error": (C.c_char_p, []),
+        "orc_mat4_identity": (None, [P(Mat4)]),
+        "orc_mat4_translate": (None, [dbl, dbl, dbl, P(Mat4)]),
+        "orc_mat4_scale": (None, [dbl, dbl, dbl, P(Mat4)]),
+        "orc_mat4_rotate_x": (None, [dbl, P(Mat4)]),
+        "orc_mat4_rotate_y": (None, [dbl, P(Mat4)]),
+        "orc_mat4_rotate_z": (None, [dbl, P(Mat4)]),
+        "orc_mat4_shear": (None, [dbl] * 6 + [P(Mat4)]),
+        "orc_mat4_mul": (None, [P(Mat4), P(Mat4), P(Mat4)]),
+        "orc_mat4_mul_point": (None, [P(Mat4), P(Vec3), P(Vec3)]),
+        "orc_mat4_mul_vector": (None, [P(Mat4), P(Vec3), P(Vec3)]),
+        "orc_mat4_transpose": (None, [P(Mat4), P(Mat4)]),
+        "orc_mat4_determinant": (dbl, [P(Mat4)]),
+        "orc_mat4_minor": (dbl, [P(Mat4), i32, i32]),
+        "orc_mat4_cofactor": (dbl, [P(Mat4), i32, i32]),
+        "orc_mat4_inverse": (i32, [P(Mat4), P(Mat4)]),
+        "orc_mat4_equal": (i32, [P(Mat4), P(Mat4)]),
+        "orc_vec_magnitude": (dbl, [P(Vec3)]),
+        "orc_vec_normalize": (None, [P(Vec3), P(Vec3)]),
+        "orc_vec_dot": (dbl, [P(Vec3), P(Vec3)]),
+        "orc_vec_cross": (None, [P(Vec3), P(Vec3), P(Vec3)]),
+        "orc_vec_reflect": (None, [P(Vec3), P(Vec3), P(Vec3)]),
+        "orc_view_transform": (None, [P(Vec3), P(Vec3), P(Vec3), P(Mat4)]),
+        "orc_ray_position": (None, [P(Ray), dbl, P(Vec3)]),
+        "orc_ray_transform": (None, [P(Ray), P(Mat4), P(Ray)]),
+        "orc_local_intersect": (i32, [i32, dbl, dbl, i32, P(Ray), P(dbl)]),
+        "orc_local_normal_at": (None, [i32, dbl, dbl, P(Vec3), P(Vec3)]),
+        "orc_shape_bounds": (None, [i32, dbl, dbl, P(Bounds)]),
+        "orc_bounds_empty": (None, [P(Bounds)]),
+        "orc_bounds_infinite": (None, [P(Bounds)]),
+        "orc_bounds_add_point": (None, [P(Bounds), P(Vec3)]),
+        "orc_bounds_merge": (None, [P(Bounds), P(Bounds), P(Bounds)]),
+        "orc_bounds_transform": (None, [P(Bounds), P(Mat4), P(Bounds)]),
+        "orc_bounds_intersects": (i32, [P(Bounds), P(Ray)]),
+        "orc_material_default": (None, [P(Material)]),
+        "orc_pattern_color_at": (None, [P(Pattern), P(Vec3), P(Color)]),
+        "orc_world_new": (vp, []),
+        "orc_world_free": (None, [vp]),
+        "orc_world_set_light": (None, [vp, P(Vec3), P(Color)]),
+        "orc_world_clear_light": (None, [vp]),
+        "orc_world_add": (i32, [vp, i32, i32, P(Mat4), P(Material), dbl, dbl, i32]),
+        "orc_world_finalize": (i32, [vp]),
+        "orc_world_set_mode": (None, [vp, i32]),
+        "orc_world_object_count": (i32, [vp]),
+        "orc_world_object_world_transform": (i32, [vp, i32, P(Mat4)]),
+        "orc_world_object_material": (i32, [vp, i32, P(Material)]),
+        "orc_world_group_bounds": (i32, [vp, i32, P(Bounds)]),
+        "orc_build_transform": (None, [P(TransformCfg), i32, P(Mat4)]),
+        "orc_build_camera": (i32, [P(CameraCfg), P(Camera)]),
+        "orc_build_world": (vp, [P(ObjectCfg), i32, P(dbl), P(dbl)]),
+        "orc_world_intersect": (i32, [vp, P(Ray), P(dbl), P(C.c_int32), i32, P(Counters)]),
+        "orc_world_hit": (i32, [vp, P(Ray), P(dbl), P(C.c_int32), P(Counters)]),
+        "orc_object_normal_at": (None, [vp, i32, P(Vec3), P(Vec3)]),
+        "orc_prepare_computations": (None, [vp, i32, dbl, P(Ray), P(Comps)]),
+        "orc_prepare_computations_for_intersections": (None, [vp, i32, dbl, P(Ray), P(dbl), P(C.c_int32), i32,
+                                                               P(Comps)]),
+        "orc_schlick": (dbl, [P(Comps)]),
+        "orc_lighting": (None, [vp, i32, P(Material), P(Vec3), P(Color), P(Vec3), P(Vec3), P(Vec3), i32, P(Color),
+                                P(Counters)]),
+        "orc_pattern_color_at_object": (None, [vp, i32, P(Pattern), P(Vec3), P(Color)]),
+        "orc_is_shadowed": (i32, [vp, P(Vec3), P(Counters)]),
+        "orc_shade_hit": (None, [vp, P(Comps), i32, P(Color), P(Counters)]),
+        "orc_color_at": (None, [vp, P(Ray), i32, P(Color), P(Counters)]),
+        "orc_reflected_color": (None, [vp, P(Comps), i32, P(Color), P(Counters)]),
+        "orc_refracted_color": (None, [vp, P(Comps), i32, P(Color), P(Counters)]),
+        "orc_camera_new": (None, [C.c_uint32, C.c_uint32, dbl, P(Camera)]),
+        "orc_camera_ray_for_pixel": (None, [P(Camera), C.c_uint32, C.c_uint32, P(Ray)]),
+        "orc_camera_render_rows": (None, [P(Camera), vp, C.c_uint32, C.c_uint32, P(dbl), P(Counters)]),
+        "orc_quantize": (C.c_uint32, [dbl]),
+        "orc_canvas_quantize": (None, [P(dbl), C.c_size_t, P(C.c_uint8)]),
+        "orc_canvas_to_ppm": (C.c_size_t, [P(dbl), C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+# ----------------------------------------------------------------------------- convenience constructors
+def vec(x, y, z) -> Vec3:
+    return Vec3(float(x), float(y), float(z))
+
+
+def color(r, g, b) -> Color:
+    return Color(float(r), float(g), float(b))
+
+
+def ray(o, d) -> Ray:
+    return Ray(vec(*o), vec(*d))
+
+
+def identity() -> Mat4:
+    m = Mat4()
+    lib().orc_mat4_identity(C.byref(m))
+    return m
+
+
+def translate(x, y, z) -> Mat4:
+    m = Mat4()
+    lib().orc_mat4_translate(x, y, z, C.byref(m))
+    return m
+
+
+def scale(x, y, z) -> Mat4:
+    m = Mat4()
+    lib().orc_mat4_scale(x, y, z, C.byref(m))
+    return m
+
+
+def rotate_x(r) -> Mat4:
+    m = Mat4()
+    lib().orc_mat4_rotate_x(r, C.byref(m))
+    return m
+
+
+def rotate_y(r) -> Mat4:
+    m = Mat4()
+    lib().orc_mat4_rotate_y(r, C.byref(m))
+    return m
+
+
+def rotate_z(r) -> Mat4:
+    m = Mat4()
+    lib().orc_mat4_rotate_z(r, C.byref(m))
+    return m
+
+
+def shear(*a) -> Mat4:
+    m = Mat4()
+    lib().orc_mat4_shear(*[float(v) for v in a], C.byref(m))
+    return m
+
+
+def mul(a: Mat4, b: Mat4) -> Mat4:
+    m = Mat4()
+    lib().orc_mat4_mul(C.byref(a), C.byref(b), C.byref(m))
+    return m
+
+
+def inverse(a: Mat4) -> Optional[Mat4]:
+    m = Mat4()
+    return m if lib().orc_mat4_inverse(C.byref(a), C.byref(m)) else None
+
+
+def default_material() -> Material:
+    m = Material()
+    lib().orc_material_default(C.byref(m))
+    return m
+
+
+def material(**kw) -> Material:
+    m = default_material()
+    for k, v in kw.items():
+        if k == "color":
+            m.color = color(*v)
+        elif k == "pattern":
+            m.pattern = v
+        else:
+            setattr(m, k, float(v))
+    return m
+
+
+def pattern(kind: int, a=(1, 1, 1), b=(0, 0, 0), transform: Optional[Mat4] = None) -> Pattern:
+    p = Pattern()
+    p.kind = kind
+    p.a = color(*a)
+    p.b = color(*b)
+    p.transform = transform if transform is not None else identity()
+    return p
+
+
+class World:
+    """Owns an orc_world.  Mirrors rendering/world.rs `World` for the known-answer tests."""
+
+    def __init__(self, handle=None):
+        self._h = handle if handle is not None else lib().orc_world_new()
+        self._dirty = True
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_world_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- construction
+    def set_light(self, position, intensity) -> None:
+        lib().orc_world_set_light(self._h, C.byref(vec(*position)), C.byref(color(*intensity)))
+
+    def clear_light(self) -> None:
+        lib().orc_world_clear_light(self._h)
+
+    def add(self, kind: int, transform: Optional[Mat4] = None, mat: Optional[Material] = None, parent: int = -1,
+            minimum: float = -math.inf, maximum: float = math.inf, closed: bool = False) -> int:
+        t = transform if transform is not None else identity()
+        m = mat if mat is not None else default_material()
+        oid = lib().orc_world_add(self._h, parent, kind, C.byref(t), C.byref(m), minimum, maximum, int(closed))
+        if oid < 0:
+            raise ValueError(lib().orc_last_error().decode())
+        self._dirty = True
+        return oid
+
+    def finalize(self) -> None:
+        if self._dirty:
+            if lib().orc_world_finalize(self._h):
+                raise ValueError(lib().orc_last_error().decode())
+            self._dirty = False
+
+    def set_mode(self, mode: int) -> None:
+        lib().orc_world_set_mode(self._h, mode)
+
+    @staticmethod
+    def default() -> "World":
+        """rendering/world.rs:201-232"""
+        w = World()
+        w.set_light((-10, 10, -10), (1, 1, 1))
+        w.add(SPHERE, identity(), material(color=(0.8, 1.0, 0.6), diffuse=0.7, specular=0.2))
+        w.add(SPHERE, scale(0.5, 0.5, 0.5))
+        return w
+
+    # -- queries
+    def world_transform(self, oid: int) -> Mat4:
+        self.finalize()
+        m = Mat4()
+        lib().orc_world_object_world_transform(self._h, oid, C.byref(m))
+        return m
+
+    def object_material(self, oid: int) -> Material:
+        m = Material()
+        lib().orc_world_object_material(self._h, oid, C.byref(m))
+        return m
+
+    def group_bounds(self, oid: int) -> Bounds:
+        self.finalize()
+        b = Bounds()
+        if lib().orc_world_group_bounds(self._h, oid, C.byref(b)):
+            raise ValueError("not a group")
+        return b
+
+    def object_count(self) -> int:
+        return lib().orc_world_object_count(self._h)
+
+    def intersect(self, r: Ray, counters: Optional[Counters] = None) -> List[Tuple[float, int]]:
+        self.finalize()
+        cap = 4 * max(1, self.object_count())
+        ts = (C.c_double * cap)()
+        ids = (C.c_int32 * cap)()
+        n = lib().orc_world_intersect(self._h, C.byref(r), ts, ids, cap, C.byref(counters) if counters else None)
+        return [(ts[i], ids[i]) for i in range(min(n, cap))]
+
+    def hit(self, r: Ray) -> Optional[Tuple[float, int]]:
+        self.finalize()
+        t = C.c_double()
+        i = C.c_int32()
+        if lib().orc_world_hit(self._h, C.byref(r), C.byref(t), C.byref(i), None):
+            return (t.value, i.value)
+        return None
+
+    def normal_at(self, oid: int, p) -> Tuple[float, float, float]:
+        self.finalize()
+        out = Vec3()
+        lib().orc_object_normal_at(self._h, oid, C.byref(vec(*p)), C.byref(out))
+        return out.tuple()
+
+    def prepare_computations(self, oid: int, t: float, r: Ray, xs: Optional[Sequence[Tuple[float, int]]] = None) -> Comps:
+        self.finalize()
+        c = Comps()
+        if xs is None:
+            lib().orc_prepare_computations(self._h, oid, t, C.byref(r), C.byref(c))
+        else:
+            n = len(xs)
+            ts = (C.c_double * n)(*[x[0] for x in xs])
+            ids = (C.c_int32 * n)(*[x[1] for x in xs])
+            lib().orc_prepare_computations_for_intersections(self._h, oid, t, C.byref(r), ts, ids, n, C.byref(c))
+        return c
+
+    def shade_hit(self, comps: Comps, remaining: int = 5) -> Tuple[float, float, float]:
+        self.finalize()
+        out = Color()
+        lib().orc_shade_hit(self._h, C.byref(comps), remaining, C.byref(out), None)
+        return out.tuple()
+
+    def color_at(self, r: Ray, remaining: int = 5, counters: Optional[Counters] = None) -> Tuple[float, float, float]:
+        self.finalize()
+        out = Color()
+        lib().orc_color_at(self._h, C.byref(r), remaining, C.byref(out), C.byref(counters) if counters else None)
+        return out.tuple()
+
+    def is_shadowed(self, p) -> bool:
+        self.finalize()
+        return bool(lib().orc_is_shadowed(self._h, C.byref(vec(*p)), None))
+
+    def reflected_color(self, comps: Comps, remaining: int = 5) -> Tuple[float, float, float]:
+        self.finalize()
+        out = Color()
+        lib().orc_reflected_color(self._h, C.byref(comps), remaining, C.byref(out), None)
+        return out.tuple()
+
+    def refracted_color(self, comps: Comps, remaining: int = 5) -> Tuple[float, float, float]:
+        self.finalize()
+        out = Color()
+        lib().orc_refracted_color(self._h, C.byref(comps), remaining, C.byref(out), None)
+        return out.tuple()
+
+    def lighting(self, oid: int, mat: Material, light_pos, light_int, point, eye, normal, in_shadow: bool):
+        self.finalize()
+        out = Color()
+        lib().orc_lighting(self._h, oid, C.byref(mat), C.byref(vec(*light_pos)), C.byref(color(*light_int)),
+                           C.byref(vec(*point)), C.byref(vec(*eye)), C.byref(vec(*normal)), int(in_shadow),
+                           C.byref(out), None)
+        return out.tuple()
+
+    def pattern_color_at_object(self, oid: int, pat: Pattern, point):
+        self.finalize()
+        out = Color()
+        lib().orc_pattern_color_at_object(self._h, oid, C.byref(pat), C.byref(vec(*point)), C.byref(out))
+        return out.tuple()
+
+
+def camera(hsize: int, vsize: int, fov: float, transform: Optional[Mat4] = None) -> Camera:
+    cam = Camera()
+    lib().orc_camera_new(hsize, vsize, fov, C.byref(cam))
+    if transform is not None:
+        cam.transform = transform
+    return cam
+
+
+def ray_for_pixel(cam: Camera, px: int, py: int) -> Ray:
+    r = Ray()
+    lib().orc_camera_ray_for_pixel(C.byref(cam), px, py, C.byref(r))
+    return r
+
+
+def render(cam: Camera, world: World, threads: int = 1, rows: Optional[Tuple[int, int]] = None,
+           counters: Optional[Counters] = None) -> np.ndarray:
+    """Camera::render (rendering/camera.rs:56-67) -> float64 array [vsize, hsize, 3] (Canvas.pixels layout).
+
+    threads == 1 is the reference's own schedule (one serial loop).  threads > 1 splits the rows into bands
+    rendered by that many OS threads (ctypes releases the GIL); the per-pixel arithmetic is unchanged.
+    """
+    world.finalize()
+    h, w = cam.vsize, cam.hsize
+    out = np.zeros((h, w, 3), dtype=np.float64)
+    ptr = out.ctypes.data_as(C.POINTER(C.c_double))
+    y0, y1 = rows if rows is not None else (0, h)
+    L = lib()
+    if threads <= 1:
+        L.orc_camera_render_rows(C.byref(cam), world._h, y0, y1, ptr, C.byref(counters) if counters else None)
+        return out
+    band = 4
+    jobs = [(y, min(y + band, y1)) for y in range(y0, y1, band)]
+    lock = threading.Lock()
+    per_thread = [Counters() for _ in range(threads)]
+
+    def work(k: int) -> None:
+        while True:
+            with lock:
+                if not jobs:
+                    return
+                a, b = jobs.pop(0)
+            L.orc_camera_render_rows(C.byref(cam), world._h, a, b, ptr, C.byref(per_thread[k]))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if counters is not None:
+        for pc in per_thread:
+            counters.add(pc)
+    return out
+
+
+def quantize(rgb: np.ndarray) -> np.ndarray:
+    """Canvas quantiser (rendering/canvas.rs:123-130) -> uint8 array of the same shape."""
+    flat = np.ascontiguousarray(rgb, dtype=np.float64).reshape(-1)
+    out = np.empty(flat.shape, dtype=np.uint8)
+    lib().orc_canvas_quantize(flat.ctypes.data_as(C.POINTER(C.c_double)), flat.size,
+                              out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out.reshape(rgb.shape)
+
+
+def to_ppm(rgb: np.ndarray) -> bytes:
+    """Canvas::to_ppm_string (rendering/canvas.rs:44-90)."""
+    a = np.ascontiguousarray(rgb, dtype=np.float64)
+    h, w = a.shape[0], a.shape[1]
+    ptr = a.ctypes.data_as(C.POINTER(C.c_double))
+    n = lib().orc_canvas_to_ppm(ptr, w, h, None, 0)
+    buf = C.create_string_buffer(n)
+    lib().orc_canvas_to_ppm(ptr, w, h, buf, n)
+    return buf.raw[:n]
+
+
+# ----------------------------------------------------------------------------- scenes/loader.rs via tomli
+def _transform_cfg(tbl: Optional[dict]) -> TransformCfg:
+    t = TransformCfg()
+    if not tbl:
+        return t
+    if "translate" in tbl:
+        t.has_translate = 1
+        t.translate[:] = [float(v) for v in tbl["translate"]]
+    if "scale" in tbl:
+        t.has_scale = 1
+        t.scale[:] = [float(v) for v in tbl["scale"]]
+    for k in ("rotate_x", "rotate_y", "rotate_z"):
+        if k in tbl:
+            setattr(t, "has_" + k, 1)
+            setattr(t, k, float(tbl[k]))
+    return t
+
+
+def _material_cfg(tbl: dict) -> MaterialCfg:
+    m = MaterialCfg()
+    m.color[:] = [float(v) for v in tbl.get("color", [1.0, 1.0, 1.0])]
+    m.ambient = float(tbl.get("ambient", 0.1))
+    m.diffuse = float(tbl.get("diffuse", 0.9))
+    m.specular = float(tbl.get("specular", 0.9))
+    m.shininess = float(tbl.get("shininess", 200.0))
+    m.reflectivity = float(tbl.get("reflectivity", 0.0))
+    m.transparency = float(tbl.get("transparency", 0.0))
+    m.refractive_index = float(tbl.get("refractive_index", 1.0))
+    m.pattern_kind = PAT_NONE
+    pat = tbl.get("pattern")
+    if pat is not None:
+        m.pattern_kind = PATTERN_BY_NAME[pat["type"]]
+        m.color_a[:] = [float(v) for v in pat["color_a"]]
+        m.color_b[:] = [float(v) for v in pat["color_b"]]
+        m.pattern_transform = _transform_cfg(pat)
+    return m
+
+
+def _flatten_objects(objs: Iterable[dict], out: List[ObjectCfg]) -> None:
+    for o in objs:
+        c = ObjectCfg()
+        c.kind = KIND_BY_NAME[o["type"]]
+        if "transform" in o:
+            c.has_transform = 1
+            c.transform = _transform_cfg(o["transform"])
+        if "material" in o:
+            c.has_material = 1
+            c.material = _material_cfg(o["material"])
+        if c.kind in (CYLINDER, CONE):
+            if "minimum" in o:
+                c.has_minimum, c.minimum = 1, float(o["minimum"])
+            if "maximum" in o:
+                c.has_maximum, c.maximum = 1, float(o["maximum"])
+            if "closed" in o:
+                c.has_closed, c.closed = 1, int(bool(o["closed"]))
+        out.append(c)
+        if c.kind == GROUP:
+            kids = o.get("children", [])
+            c.n_children = len(kids)
+            _flatten_objects(kids, out)
+
+
+def load_scene(path: str, width: Optional[int] = None, height: Optional[int] = None) -> Tuple[Camera, World]:
+    """SceneFile::from_file + build_camera + build_world (scenes/loader.rs:189-248), optionally overriding the
+    camera's width/height (the "upscaled to 3840x2160" configurations replace exactly those two integers)."""
+    import tomli
+
+    with open(path, "rb") as f:
+        doc = tomli.load(f)
+    return scene_from_dict(doc, width, height)
+
+
+def scene_from_dict(doc: dict, width: Optional[int] = None, height: Optional[int] = None) -> Tuple[Camera, World]:
+    cc = CameraCfg()
+    cam = doc["camera"]
+    cc.width = int(width if width is not None else cam["width"])
+    cc.height = int(height if height is not None else cam["height"])
+    cc.fov = float(cam["fov"])
+    cc.from_[:] = [float(v) for v in cam["from"]]
+    cc.to[:] = [float(v) for v in cam["to"]]
+    cc.up[:] = [float(v) for v in cam["up"]]
+    camera_out = Camera()
+    lib().orc_build_camera(C.byref(cc), C.byref(camera_out))
+
+    flat: List[ObjectCfg] = []
+    _flatten_objects(doc["objects"], flat)
+    arr = (ObjectCfg * max(1, len(flat)))(*flat)
+    lp = (C.c_double * 3)(*[float(v) for v in doc["light"]["position"]])
+    li = (C.c_double * 3)(*[float(v) for v in doc["light"]["intensity"]])
+    h = lib().orc_build_world(arr, len(flat), lp, li)
+    if not h:
+        raise ValueError(lib().orc_last_error().decode())
+    w = World(handle=h)
+    w._dirty = False
+    return camera_out, w
