@@ -1,0 +1,195 @@
+/*
+ * raytracer_rs_amd.h -- C ABI of the MI355X (gfx950) renderer for raytracer-rs's per-pixel render path.
+ *
+ * The reference crate has no FFI of its own: the boundary it offers is the Rust API
+ * `SceneFile -> (Camera, World) -> Camera::render(&World) -> Canvas`.  These entry points are what a `-sys`
+ * binding under that API calls; each one names the reference item it stands in for (file:line under the
+ * reference checkout, `src/` omitted).
+ *
+ * Conventions
+ *   - plain C types only; every function returns RT_OK (0) or a negative RT_ERR_* code and never aborts or
+ *     throws across the boundary; rt_last_error() returns the message of the calling thread's last failure.
+ *   - matrices are 16 doubles, row-major, exactly `Matrix4.data` (core/matrices.rs:7-9).
+ *   - colours/framebuffers are 3 doubles per pixel, row-major, index (y*width + x)*3: the layout of
+ *     `Canvas.pixels` (rendering/canvas.rs:7-11,40-42).
+ *   - objects are listed in depth-first pre-order: a group (rendering/objects.rs:34-41, geometry/groups.rs:15-21)
+ *     is followed by its `n_children` children, each of which may itself be a group.
+ *   - all arithmetic on the path is IEEE f64 without multiply-add contraction, in the reference's operation order.
+ *   - the caller owns every output buffer; handles are opaque; a handle is bound to the HIP device it was created
+ *     on and serves one call at a time.
+ *   - there is no CPU fallback: without a HIP device every rendering entry point fails with RT_ERR_NO_DEVICE.
+ */
+#ifndef RAYTRACER_RS_AMD_H
+#define RAYTRACER_RS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1,
+    RT_ERR_NOT_INVERTIBLE = -2, /* the reference panics: "... should be invertible" (objects.rs:88-101,123-125; world.rs:54-57; camera.rs:46-49; patterns.rs:140-143) */
+    RT_ERR_MATERIAL = -3,       /* the reference panics: "Material values must be positive" (scene/materials.rs:94-96) */
+    RT_ERR_HIP = -4,
+    RT_ERR_IO = -5,             /* SceneFile::from_file Err: fs::read_to_string (scenes/loader.rs:191) */
+    RT_ERR_PARSE = -6,          /* SceneFile::from_file Err: toml::from_str (scenes/loader.rs:192) */
+    RT_ERR_UNSUPPORTED = -7,    /* e.g. groups nested deeper than RT_MAX_GROUP_NESTING */
+    RT_ERR_NO_DEVICE = -8
+};
+
+/* enum Object (rendering/objects.rs:34-41) */
+enum { RT_SPHERE = 0, RT_PLANE = 1, RT_CUBE = 2, RT_CYLINDER = 3, RT_CONE = 4, RT_GROUP = 5 };
+/* enum PatternKind (scene/patterns.rs:13-32); RT_PATTERN_NONE is Option::None (scene/materials.rs:18) */
+enum { RT_PATTERN_NONE = -1, RT_PATTERN_STRIPE = 0, RT_PATTERN_GRADIENT = 1, RT_PATTERN_RING = 2, RT_PATTERN_CHECKERS = 3 };
+
+/* Groups may be nested this deep below a top-level group (a leaf inside a top-level group is at depth 1). */
+#define RT_MAX_GROUP_NESTING 3
+/* DEFAULT_MAX_REFLECTION_DEPTH == DEFAULT_MAX_REFRACTION_DEPTH (rendering/world.rs:11-12) */
+#define RT_DEFAULT_DEPTH 5
+#define RT_MAX_DEPTH 8
+
+typedef struct rt_pattern_desc { /* struct Pattern (scene/patterns.rs:7-10) */
+    int32_t kind;                /* RT_PATTERN_* */
+    int32_t _pad;
+    double transform[16];
+    double color_a[3];
+    double color_b[3];
+} rt_pattern_desc;
+
+typedef struct rt_material_desc { /* struct Material (scene/materials.rs:9-19) */
+    double color[3];
+    double ambient, diffuse, specular, shininess, reflectivity, transparency, refractive_index;
+    rt_pattern_desc pattern;
+} rt_material_desc;
+
+typedef struct rt_object_desc { /* one `Object` (rendering/objects.rs:34-41) */
+    int32_t kind;               /* RT_SPHERE .. RT_GROUP */
+    int32_t n_children;         /* groups only: Group.children.len() (geometry/groups.rs:20) */
+    int32_t closed;             /* Cylinder/Cone.closed (geometry/cylinders.rs:21, cones.rs:21) */
+    int32_t _pad;
+    double minimum, maximum;    /* Cylinder/Cone.minimum/maximum; ignored for other kinds */
+    double transformation[16];       /* Transformable::transformation() (objects.rs:212-221) */
+    double world_transformation[16]; /* Object::world_transformation() (objects.rs:241-250) */
+    rt_material_desc material;       /* HasMaterial::material() (objects.rs:188-197) */
+} rt_object_desc;
+
+typedef struct rt_world_desc { /* struct World (rendering/world.rs:14-17) */
+    const rt_object_desc *objects; /* all objects, depth-first pre-order */
+    uint32_t n_objects;
+    int32_t has_light;             /* light_source.is_some() */
+    double light_position[3];      /* PointLight.position (scene/lights.rs:5-8) */
+    double light_intensity[3];     /* PointLight.intensity */
+} rt_world_desc;
+
+typedef struct rt_camera_desc { /* struct Camera (rendering/camera.rs:8-16) */
+    uint32_t hsize, vsize;
+    double field_of_view;
+    double transform[16];
+    double pixel_size, half_width, half_height;
+} rt_camera_desc;
+
+/* Operation counts of one call.  `rays` counts World::intersect invocations (rendering/world.rs:27): camera rays,
+ * shadow rays, reflection rays and refraction rays. */
+typedef struct rt_stats {
+    uint64_t rays, primary, shadow, reflect, refract;
+    uint64_t prim_tests[5]; /* Shape::local_intersect calls per leaf kind */
+    uint64_t prim_hits[5];  /* ... that returned at least one t */
+    uint64_t aabb_tests;    /* Bounds::intersects calls */
+    uint64_t ray_transforms;/* Ray::transform calls */
+    uint64_t shades;        /* shade_hit calls */
+    uint64_t lit;           /* lighting() calls that took the diffuse branch */
+    uint64_t specular;      /* ... that evaluated powf */
+    uint64_t patterns;      /* Pattern::color_at_object calls */
+    uint64_t refract_setups;/* refracted_color calls past the two early-outs */
+    uint64_t schlick;       /* Computations::schlick calls */
+    double kernel_ms;       /* device time of the kernel(s), by HIP events (0 for the asynchronous entry point) */
+} rt_stats;
+
+typedef struct rt_render_opts {
+    uint32_t row_begin, row_end; /* rows [row_begin, row_end) of the frame; both 0 = the whole frame */
+    int32_t max_depth;           /* recursion budget per pixel; 0 = RT_DEFAULT_DEPTH */
+    int32_t collect_stats;       /* non-zero: run the counting variant of the kernel and fill rt_stats */
+    void *stream;                /* hipStream_t for rt_render_device; NULL = the null stream */
+} rt_render_opts;
+
+typedef struct rt_scene_info {
+    uint32_t n_objects, n_leaves, n_groups, max_nesting;
+    uint64_t device_bytes;
+    int32_t device;
+    int32_t _pad;
+} rt_scene_info;
+
+typedef struct rt_scene rt_scene;           /* a World resident on one GPU */
+typedef struct rt_scene_file rt_scene_file; /* struct SceneFile (scenes/loader.rs:21-26) */
+
+const char *rt_last_error(void);
+int rt_abi_version(void);
+/* Number of HIP devices visible to the process. */
+int rt_device_count(int *count);
+
+/* Copies a World into device memory: pre-inverts every transformation with the reference's cofactor algorithm
+ * (core/matrices.rs:94-162), computes every group's bounds (geometry/groups.rs:130-149, geometry/bounds.rs:36-89)
+ * and uploads the flattened tables.  Stands in for the `&World` borrow of Camera::render (rendering/camera.rs:56).
+ * device < 0 selects the process's current HIP device. */
+int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out);
+void rt_scene_destroy(rt_scene *scene);
+int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
+
+/* Camera::render (rendering/camera.rs:56-67): writes rows [row_begin,row_end) of the frame into the host buffer
+ * `rgb` (which holds the WHOLE frame: hsize*vsize*3 doubles; rows outside the range are left untouched). */
+int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts, double *rgb,
+              rt_stats *stats);
+/* The same on device memory, asynchronously on opts->stream: `rgb_device` receives only the rows rendered,
+ * (row_end-row_begin)*hsize*3 doubles starting at row_begin.  No host synchronisation unless collect_stats is set. */
+int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
+                     double *rgb_device, rt_stats *stats);
+
+/* World::color_at (rendering/world.rs:113-126) for n rays (6 doubles each: origin xyz, direction xyz) with the
+ * given recursion budget (world.rs:117 `remaining`; pass RT_DEFAULT_DEPTH for color_at itself). */
+int rt_color_at(const rt_scene *scene, const double *rays, uint32_t n, int32_t remaining, double *colors,
+                rt_stats *stats);
+/* World::intersect + Intersection::hit (rendering/world.rs:27-36, rendering/intersections.rs:37-39) for n rays:
+ * t[i] and the index (into rt_world_desc.objects) of the hit object, or -1 / NaN when nothing is hit. */
+int rt_intersect(const rt_scene *scene, const double *rays, uint32_t n, double *t, int32_t *object);
+/* World::is_shadowed (rendering/world.rs:128-149) for n points (3 doubles each). */
+int rt_is_shadowed(const rt_scene *scene, const double *points, uint32_t n, uint8_t *shadowed);
+/* Object::normal_at (rendering/objects.rs:171-184) of object[i] at points[i]. */
+int rt_normal_at(const rt_scene *scene, const int32_t *object, const double *points, uint32_t n, double *normals);
+/* Camera::ray_for_pixel (rendering/camera.rs:39-54) for n pixels, evaluated by the device code path. */
+int rt_ray_for_pixel(const rt_camera_desc *camera, const uint32_t *px, const uint32_t *py, uint32_t n, double *rays,
+                     int device);
+
+/* Camera::new (rendering/camera.rs:19-37). */
+int rt_camera_new(uint32_t hsize, uint32_t vsize, double field_of_view, rt_camera_desc *out);
+/* view_transform (scene/transformations.rs:4-17). */
+int rt_view_transform(const double from[3], const double to[3], const double up[3], double out[16]);
+
+/* Canvas::to_ppm_string (rendering/canvas.rs:44-90): P3 text into `out` (capacity cap); returns the length
+ * needed, so a first call with out = NULL sizes the buffer. */
+size_t rt_canvas_to_ppm(const double *rgb, uint32_t width, uint32_t height, char *out, size_t cap);
+/* Canvas::to_ppm (rendering/canvas.rs:116-120). */
+int rt_canvas_write_ppm(const double *rgb, uint32_t width, uint32_t height, const char *path);
+/* convert_canvas_color_value_to_decimal_rgb_value (rendering/canvas.rs:123-130) over n values. */
+int rt_canvas_quantize(const double *rgb, size_t n, uint8_t *out);
+
+/* SceneFile::from_file (scenes/loader.rs:190-194): reads and parses a TOML scene. */
+int rt_scene_file_load(const char *path, rt_scene_file **out);
+/* The same from memory (the text of a scene file). */
+int rt_scene_file_parse(const char *text, size_t len, rt_scene_file **out);
+void rt_scene_file_free(rt_scene_file *file);
+/* SceneFile::build_camera (scenes/loader.rs:196-212). */
+int rt_scene_file_build_camera(const rt_scene_file *file, rt_camera_desc *out);
+/* SceneFile::build_world (scenes/loader.rs:214-247).  The object array belongs to the file handle and stays
+ * valid until rt_scene_file_free. */
+int rt_scene_file_build_world(rt_scene_file *file, rt_world_desc *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACER_RS_AMD_H */

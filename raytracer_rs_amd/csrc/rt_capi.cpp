@@ -1,0 +1,416 @@
+// C ABI of include/raytracer_rs_amd.h over the HIP runtime.  No CPU rendering path exists in this library: every
+// rendering entry point needs a HIP device and fails with RT_ERR_NO_DEVICE / RT_ERR_HIP otherwise.
+#include <hip/hip_runtime_api.h>
+
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/raytracer_rs_amd.h"
+#include "rt_device.hpp"
+#include "rt_flatten.hpp"
+#include "rt_loader.hpp"
+#include "rt_math.hpp"
+
+struct rt_scene {
+    int device = 0;
+    rt::FlatScene flat;
+    RtNode *d_nodes = nullptr;
+    RtSurface *d_surfaces = nullptr;
+    unsigned long long *d_counters = nullptr;
+    rt::DeviceScene dev;
+    std::vector<int32_t> object_to_leaf;
+    uint64_t device_bytes = 0;
+};
+
+struct rt_scene_file {
+    rt::SceneFile file;
+    std::vector<rt_object_desc> objects;
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+int set_error(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+int hip_error(hipError_t e, const char *what) {
+    return set_error(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? RT_ERR_NO_DEVICE : RT_ERR_HIP,
+                     std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return hip_error(_e, #expr); \
+    } while (0)
+
+// Makes `device` current for the scope and restores the previous device afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t status = hipSuccess;
+    explicit DeviceGuard(int device) {
+        status = hipGetDevice(&prev);
+        if (status == hipSuccess && prev != device) {
+            status = hipSetDevice(device);
+            switched = status == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+template <typename T>
+struct DeviceBuffer {
+    T *p = nullptr;
+    ~DeviceBuffer() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) { return hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)); }
+};
+
+void stats_from_counters(const unsigned long long *c, rt_stats *s) {
+    s->rays = c[0]; s->primary = c[1]; s->shadow = c[2]; s->reflect = c[3]; s->refract = c[4];
+    for (int i = 0; i < 5; ++i) { s->prim_tests[i] = c[5 + i]; s->prim_hits[i] = c[10 + i]; }
+    s->aabb_tests = c[15]; s->ray_transforms = c[16]; s->shades = c[17]; s->lit = c[18]; s->specular = c[19];
+    s->patterns = c[20]; s->refract_setups = c[21]; s->schlick = c[22];
+}
+
+int clamp_depth(int d) {
+    if (d <= 0) return RT_DEFAULT_DEPTH;
+    return d > RT_MAX_DEPTH ? RT_MAX_DEPTH : d;
+}
+
+int render_rows(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts, uint32_t &row_begin,
+                uint32_t &row_end, int &depth, RtCameraDev &cam) {
+    if (!scene || !camera) return set_error(RT_ERR_INVALID_ARGUMENT, "scene and camera must not be NULL");
+    if (camera->hsize == 0 || camera->vsize == 0) return set_error(RT_ERR_INVALID_ARGUMENT, "camera has zero size");
+    row_begin = 0;
+    row_end = camera->vsize;
+    depth = RT_DEFAULT_DEPTH;
+    if (opts) {
+        if (opts->row_begin || opts->row_end) {
+            row_begin = opts->row_begin;
+            row_end = opts->row_end;
+        }
+        if (opts->max_depth < 0 || opts->max_depth > RT_MAX_DEPTH)
+            return set_error(RT_ERR_INVALID_ARGUMENT, "max_depth must be within 0.." + std::to_string(RT_MAX_DEPTH));
+        depth = clamp_depth(opts->max_depth);
+    }
+    if (row_begin > row_end || row_end > camera->vsize)
+        return set_error(RT_ERR_INVALID_ARGUMENT, "row range lies outside the frame");
+    std::string err;
+    int rc = rt::camera_to_device(*camera, cam, err);
+    if (rc != RT_OK) return set_error(rc, err);
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_error.c_str(); }
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_device_count(int *count) {
+    if (!count) return set_error(RT_ERR_INVALID_ARGUMENT, "count must not be NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return hip_error(e, "hipGetDeviceCount");
+    }
+    *count = n;
+    return RT_OK;
+}
+
+int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
+    if (!world || !out) return set_error(RT_ERR_INVALID_ARGUMENT, "world and out must not be NULL");
+    *out = nullptr;
+    auto sc = std::make_unique<rt_scene>();
+    std::string err;
+    int rc = rt::flatten_world(*world, sc->flat, err);
+    if (rc != RT_OK) return set_error(rc, err);
+    sc->object_to_leaf.assign(world->n_objects, -1);
+    for (const RtNode &n : sc->flat.nodes)
+        if (n.leaf >= 0) sc->object_to_leaf[(size_t)n.object] = n.leaf;
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return set_error(RT_ERR_NO_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) return set_error(RT_ERR_NO_DEVICE, "device ordinal out of range");
+    sc->device = device;
+    DeviceGuard guard(device);
+    if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+
+    size_t nb = sc->flat.nodes.size() * sizeof(RtNode), sb = sc->flat.surfaces.size() * sizeof(RtSurface);
+    HIP_TRY(hipMalloc((void **)&sc->d_nodes, nb ? nb : sizeof(RtNode)));
+    e = hipMalloc((void **)&sc->d_surfaces, sb ? sb : sizeof(RtSurface));
+    if (e == hipSuccess) e = hipMalloc((void **)&sc->d_counters, RT_NUM_COUNTERS * sizeof(unsigned long long));
+    if (e == hipSuccess && nb) e = hipMemcpy(sc->d_nodes, sc->flat.nodes.data(), nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && sb) e = hipMemcpy(sc->d_surfaces, sc->flat.surfaces.data(), sb, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        rt_scene *raw = sc.release();
+        rt_scene_destroy(raw);
+        return hip_error(e, "uploading the scene");
+    }
+    sc->device_bytes = nb + sb + RT_NUM_COUNTERS * sizeof(unsigned long long);
+    sc->dev.nodes = sc->d_nodes;
+    sc->dev.surfaces = sc->d_surfaces;
+    sc->dev.n_nodes = (int32_t)sc->flat.nodes.size();
+    sc->dev.n_leaves = (int32_t)sc->flat.surfaces.size();
+    sc->dev.light = sc->flat.light;
+    *out = sc.release();
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene *scene) {
+    if (!scene) return;
+    {
+        DeviceGuard guard(scene->device);
+        if (scene->d_nodes) (void)hipFree(scene->d_nodes);
+        if (scene->d_surfaces) (void)hipFree(scene->d_surfaces);
+        if (scene->d_counters) (void)hipFree(scene->d_counters);
+    }
+    delete scene;
+}
+
+int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out) {
+    if (!scene || !out) return set_error(RT_ERR_INVALID_ARGUMENT, "scene and out must not be NULL");
+    std::memset(out, 0, sizeof *out);
+    out->n_objects = (uint32_t)scene->flat.nodes.size();
+    out->n_leaves = scene->flat.n_leaves;
+    out->n_groups = scene->flat.n_groups;
+    out->max_nesting = scene->flat.max_nesting;
+    out->device_bytes = scene->device_bytes;
+    out->device = scene->device;
+    return RT_OK;
+}
+
+int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
+                     double *rgb_device, rt_stats *stats) {
+    uint32_t r0, r1;
+    int depth;
+    RtCameraDev cam;
+    int rc = render_rows(scene, camera, opts, r0, r1, depth, cam);
+    if (rc != RT_OK) return rc;
+    if (!rgb_device && r1 > r0) return set_error(RT_ERR_INVALID_ARGUMENT, "rgb_device must not be NULL");
+    const bool want_stats = opts && opts->collect_stats;
+    if (want_stats && !stats) return set_error(RT_ERR_INVALID_ARGUMENT, "collect_stats needs a stats pointer");
+    hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
+    DeviceGuard guard(scene->device);
+    if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (want_stats) HIP_TRY(hipMemsetAsync(scene->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), stream));
+    HIP_TRY(rt::launch_render(scene->dev, cam, r0, r1, depth, rgb_device, want_stats ? scene->d_counters : nullptr, stream));
+    if (want_stats) {
+        unsigned long long c[RT_NUM_COUNTERS];
+        HIP_TRY(hipMemcpyAsync(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        stats_from_counters(c, stats);
+    }
+    return RT_OK;
+}
+
+int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts, double *rgb,
+              rt_stats *stats) {
+    uint32_t r0, r1;
+    int depth;
+    RtCameraDev cam;
+    int rc = render_rows(scene, camera, opts, r0, r1, depth, cam);
+    if (rc != RT_OK) return rc;
+    if (!rgb) return set_error(RT_ERR_INVALID_ARGUMENT, "rgb must not be NULL");
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (r1 == r0) return RT_OK;
+    const bool want_stats = opts && opts->collect_stats;
+    if (want_stats && !stats) return set_error(RT_ERR_INVALID_ARGUMENT, "collect_stats needs a stats pointer");
+    DeviceGuard guard(scene->device);
+    if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+    const size_t count = (size_t)(r1 - r0) * camera->hsize * 3;
+    DeviceBuffer<double> buf;
+    HIP_TRY(buf.alloc(count));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    HIP_TRY(hipEventCreate(&ev0));
+    hipError_t e = hipEventCreate(&ev1);
+    if (e == hipSuccess && want_stats) e = hipMemsetAsync(scene->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), nullptr);
+    if (e == hipSuccess) e = hipEventRecord(ev0, nullptr);
+    if (e == hipSuccess) e = rt::launch_render(scene->dev, cam, r0, r1, depth, buf.p, want_stats ? scene->d_counters : nullptr, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(ev1, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(rgb + (size_t)r0 * camera->hsize * 3, buf.p, count * sizeof(double), hipMemcpyDeviceToHost);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+    unsigned long long c[RT_NUM_COUNTERS];
+    if (e == hipSuccess && want_stats) e = hipMemcpy(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost);
+    (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (e != hipSuccess) return hip_error(e, "rt_render");
+    if (stats) {
+        if (want_stats) stats_from_counters(c, stats);
+        stats->kernel_ms = ms;
+    }
+    return RT_OK;
+}
+
+int rt_color_at(const rt_scene *scene, const double *rays, uint32_t n, int32_t remaining, double *colors,
+                rt_stats *stats) {
+    if (!scene || ((!rays || !colors) && n)) return set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (remaining < 0 || remaining > RT_MAX_DEPTH)
+        return set_error(RT_ERR_INVALID_ARGUMENT, "remaining must be within 0.." + std::to_string(RT_MAX_DEPTH));
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (!n) return RT_OK;
+    DeviceGuard guard(scene->device);
+    if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+    DeviceBuffer<double> d_rays, d_colors;
+    HIP_TRY(d_rays.alloc((size_t)n * 6));
+    HIP_TRY(d_colors.alloc((size_t)n * 3));
+    HIP_TRY(hipMemcpy(d_rays.p, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice));
+    if (stats) HIP_TRY(hipMemset(scene->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long)));
+    HIP_TRY(rt::launch_color_at(scene->dev, d_rays.p, n, remaining, d_colors.p, stats ? scene->d_counters : nullptr, nullptr));
+    HIP_TRY(hipMemcpy(colors, d_colors.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (stats) {
+        unsigned long long c[RT_NUM_COUNTERS];
+        HIP_TRY(hipMemcpy(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost));
+        stats_from_counters(c, stats);
+    }
+    return RT_OK;
+}
+
+int rt_intersect(const rt_scene *scene, const double *rays, uint32_t n, double *t, int32_t *object) {
+    if (!scene || ((!rays || !t || !object) && n)) return set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!n) return RT_OK;
+    DeviceGuard guard(scene->device);
+    if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+    DeviceBuffer<double> d_rays, d_t;
+    DeviceBuffer<int32_t> d_obj;
+    HIP_TRY(d_rays.alloc((size_t)n * 6));
+    HIP_TRY(d_t.alloc(n));
+    HIP_TRY(d_obj.alloc(n));
+    HIP_TRY(hipMemcpy(d_rays.p, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(rt::launch_intersect(scene->dev, d_rays.p, n, d_t.p, d_obj.p, nullptr));
+    HIP_TRY(hipMemcpy(t, d_t.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(object, d_obj.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_is_shadowed(const rt_scene *scene, const double *points, uint32_t n, uint8_t *shadowed) {
+    if (!scene || ((!points || !shadowed) && n)) return set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!n) return RT_OK;
+    DeviceGuard guard(scene->device);
+    if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+    DeviceBuffer<double> d_points;
+    DeviceBuffer<uint8_t> d_out;
+    HIP_TRY(d_points.alloc((size_t)n * 3));
+    HIP_TRY(d_out.alloc(n));
+    HIP_TRY(hipMemcpy(d_points.p, points, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(rt::launch_is_shadowed(scene->dev, d_points.p, n, d_out.p, nullptr));
+    HIP_TRY(hipMemcpy(shadowed, d_out.p, n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_normal_at(const rt_scene *scene, const int32_t *object, const double *points, uint32_t n, double *normals) {
+    if (!scene || ((!object || !points || !normals) && n)) return set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!n) return RT_OK;
+    std::vector<int32_t> leaf(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (object[i] < 0 || (size_t)object[i] >= scene->object_to_leaf.size() || scene->object_to_leaf[(size_t)object[i]] < 0)
+            return set_error(RT_ERR_INVALID_ARGUMENT, "Groups do not have a normal - normal_at should be called on child objects");
+        leaf[i] = scene->object_to_leaf[(size_t)object[i]];
+    }
+    DeviceGuard guard(scene->device);
+    if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+    DeviceBuffer<int32_t> d_leaf;
+    DeviceBuffer<double> d_points, d_normals;
+    HIP_TRY(d_leaf.alloc(n));
+    HIP_TRY(d_points.alloc((size_t)n * 3));
+    HIP_TRY(d_normals.alloc((size_t)n * 3));
+    HIP_TRY(hipMemcpy(d_leaf.p, leaf.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_points.p, points, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(rt::launch_normal_at(scene->dev, d_leaf.p, d_points.p, n, d_normals.p, nullptr));
+    HIP_TRY(hipMemcpy(normals, d_normals.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_ray_for_pixel(const rt_camera_desc *camera, const uint32_t *px, const uint32_t *py, uint32_t n, double *rays,
+                     int device) {
+    if (!camera || ((!px || !py || !rays) && n)) return set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    RtCameraDev cam;
+    std::string err;
+    int rc = rt::camera_to_device(*camera, cam, err);
+    if (rc != RT_OK) return set_error(rc, err);
+    if (!n) return RT_OK;
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    DeviceGuard guard(device);
+    if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+    DeviceBuffer<uint32_t> d_px, d_py;
+    DeviceBuffer<double> d_rays;
+    HIP_TRY(d_px.alloc(n));
+    HIP_TRY(d_py.alloc(n));
+    HIP_TRY(d_rays.alloc((size_t)n * 6));
+    HIP_TRY(hipMemcpy(d_px.p, px, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_py.p, py, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(rt::launch_ray_for_pixel(cam, d_px.p, d_py.p, n, d_rays.p, nullptr));
+    HIP_TRY(hipMemcpy(rays, d_rays.p, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_camera_new(uint32_t hsize, uint32_t vsize, double field_of_view, rt_camera_desc *out) {
+    if (!out) return set_error(RT_ERR_INVALID_ARGUMENT, "out must not be NULL");
+    rt::camera_new(hsize, vsize, field_of_view, *out);
+    return RT_OK;
+}
+
+int rt_view_transform(const double from[3], const double to[3], const double up[3], double out[16]) {
+    if (!from || !to || !up || !out) return set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    rt::view_transform(rt::Vec3{from[0], from[1], from[2]}, rt::Vec3{to[0], to[1], to[2]}, rt::Vec3{up[0], up[1], up[2]})
+        .to_array(out);
+    return RT_OK;
+}
+
+int rt_scene_file_load(const char *path, rt_scene_file **out) {
+    if (!path || !out) return set_error(RT_ERR_INVALID_ARGUMENT, "path and out must not be NULL");
+    *out = nullptr;
+    auto f = std::make_unique<rt_scene_file>();
+    std::string err;
+    int rc = rt::SceneFile::from_file(path, f->file, err);
+    if (rc != RT_OK) return set_error(rc, err);
+    *out = f.release();
+    return RT_OK;
+}
+
+int rt_scene_file_parse(const char *text, size_t len, rt_scene_file **out) {
+    if (!text || !out) return set_error(RT_ERR_INVALID_ARGUMENT, "text and out must not be NULL");
+    *out = nullptr;
+    auto f = std::make_unique<rt_scene_file>();
+    std::string err;
+    int rc = rt::SceneFile::from_str(std::string(text, len), f->file, err);
+    if (rc != RT_OK) return set_error(rc, err);
+    *out = f.release();
+    return RT_OK;
+}
+
+void rt_scene_file_free(rt_scene_file *file) { delete file; }
+
+int rt_scene_file_build_camera(const rt_scene_file *file, rt_camera_desc *out) {
+    if (!file || !out) return set_error(RT_ERR_INVALID_ARGUMENT, "file and out must not be NULL");
+    file->file.build_camera(*out);
+    return RT_OK;
+}
+
+int rt_scene_file_build_world(rt_scene_file *file, rt_world_desc *out) {
+    if (!file || !out) return set_error(RT_ERR_INVALID_ARGUMENT, "file and out must not be NULL");
+    std::string err;
+    int rc = file->file.build_world(file->objects, *out, err);
+    if (rc != RT_OK) return set_error(rc, err);
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,803 @@
+// gfx950 (MI355X, CDNA4) kernels of the per-pixel render path: camera ray generation, scene traversal with
+// group-AABB culling, ray/shape intersection, Phong lighting with shadow rays, patterns, and the depth-bounded
+// reflection/refraction tree with Schlick blending.  IEEE f64 throughout, compiled with -ffp-contract=off: the
+// reference (rustc) never fuses a multiply-add, and a fused one flips decisions such as `discriminant < 0.0`.
+//
+// Execution model
+//   * one lane per pixel (or per query ray); a wave of 64 lanes covers an 8x8 pixel tile so that neighbouring lanes
+//     see the same objects; 256-thread workgroups cover 16x16 pixels.
+//   * scene traversal is WAVE-UNIFORM: all lanes of a wave walk the node table with one scalar node index, so node
+//     records (inverse matrices, bounds, kind) arrive by scalar loads into SGPRs and the shape switch is a scalar
+//     branch.  A group's subtree is entered when ANY lane's ray passes the group's bounds (wave ballot); lanes whose
+//     own ray missed are masked for the subtree.  Each lane therefore tests exactly the primitives the reference
+//     tests for its ray, in the reference's order.
+//   * the recursion of World::shade_hit / color_at (rendering/world.rs:84-126) is an iterative per-lane loop with ONE
+//     traversal call site: a lane alternates between tracing a radiance ray and tracing the shadow ray of the hit it
+//     found, so lanes whose ray missed go straight on to their next pending ray.  Secondary rays carry a scalar path
+//     weight; when a hit spawns both a reflection and a refraction ray the refraction ray is parked on a per-lane
+//     stack of at most `max_depth` entries.
+//   * no MFMA: nothing on this path is a dense contraction.  No LDS: the node table is read through the scalar
+//     cache, the per-hit surface records through the vector L1.
+#include <hip/hip_runtime.h>
+
+#include "../../include/raytracer_rs_amd.h"
+#include "rt_device.hpp"
+
+namespace rt {
+namespace {
+
+#define RT_CONSTANT_AS __attribute__((address_space(4)))
+typedef const double RT_CONSTANT_AS *cdp;
+typedef const RtNode RT_CONSTANT_AS *NodeP;
+
+constexpr double EPS = 1e-5;          // core/floats.rs:2
+constexpr double AABB_EPS = 1e-10;    // geometry/bounds.rs:114
+constexpr double CHECKER_EPS = 1e-6;  // scene/patterns.rs:106
+constexpr int STACK_MAX = RT_MAX_DEPTH;
+
+enum {
+    C_RAYS = 0, C_PRIMARY, C_SHADOW, C_REFLECT, C_REFRACT,
+    C_PRIM_TESTS = 5, C_PRIM_HITS = 10,
+    C_AABB = 15, C_XFORM, C_SHADES, C_LIT, C_SPECULAR, C_PATTERNS, C_REFRACT_SETUPS, C_SCHLICK
+};
+static_assert(C_SCHLICK + 1 == RT_NUM_COUNTERS, "counter table out of step with RtCounters");
+
+template <bool STATS>
+struct Ctr {
+    unsigned c[RT_NUM_COUNTERS];
+    __device__ __forceinline__ void clear() {
+        for (int i = 0; i < RT_NUM_COUNTERS; ++i) c[i] = 0;
+    }
+    __device__ __forceinline__ void add(int i) { c[i]++; }
+};
+template <>
+struct Ctr<false> {
+    __device__ __forceinline__ void clear() {}
+    __device__ __forceinline__ void add(int) {}
+};
+
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ V3 mk(double x, double y, double z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator/(V3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
+// core/tuples.rs:59-61
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// core/tuples.rs:35-37
+__device__ __forceinline__ double magnitude(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+// core/tuples.rs:54-56: self - (normal * 2.0) * self.dot(normal)
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (n * 2.0) * dot(v, n); }
+
+// Matrix4 * Point / Vector (core/matrices.rs:195-221) on rows 0..2 of an affine matrix.  The point form adds
+// row[3]*1.0 == row[3]; the vector form would add row[3]*0.0, which can only change the sign of an exact zero and
+// is left out.
+template <typename P>
+__device__ __forceinline__ V3 mul_point(P m, V3 p) {
+    return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+              m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+template <typename P>
+__device__ __forceinline__ V3 mul_vector(P m, V3 v) {
+    return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
+              m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+// transpose(M) * Vector (rendering/objects.rs:102)
+template <typename P>
+__device__ __forceinline__ V3 mul_vector_transposed(P m, V3 v) {
+    return mk(m[0] * v.x + m[4] * v.y + m[8] * v.z, m[1] * v.x + m[5] * v.y + m[9] * v.z,
+              m[2] * v.x + m[6] * v.y + m[10] * v.z);
+}
+
+struct SceneK {
+    NodeP nodes;
+    const RtSurface *surfaces;
+    int n_nodes;
+    int max_depth;
+    RtLight light;
+};
+
+// Closest hit so far: the smallest t >= 0, the earliest emitted winning ties -- the element
+// Intersection::hit (rendering/intersections.rs:37-39) finds first in the stably sorted list (world.rs:34).
+struct Best {
+    double t;
+    int leaf;
+};
+__device__ __forceinline__ void cand(double t, int leaf, Best &b) {
+    if (t >= 0.0 && (b.leaf < 0 || t < b.t)) {
+        b.t = t;
+        b.leaf = leaf;
+    }
+}
+
+// geometry/cubes.rs:41-59 (threshold EPSILON, extents -1..1) and geometry/bounds.rs:110-128 (threshold 1e-10)
+__device__ __forceinline__ void check_axis(double origin, double direction, double lo, double hi, double threshold,
+                                           double &tmin, double &tmax) {
+    double n0 = lo - origin;
+    double n1 = hi - origin;
+    double a, b;
+    if (fabs(direction) >= threshold) {
+        a = n0 / direction;
+        b = n1 / direction;
+    } else {
+        a = n0 * INFINITY;
+        b = n1 * INFINITY;
+    }
+    if (a > b) {
+        tmin = b;
+        tmax = a;
+    } else {
+        tmin = a;
+        tmax = b;
+    }
+}
+
+// geometry/bounds.rs:94-106; v_max_f64 / v_min_f64 return the non-NaN operand like f64::max / f64::min
+__device__ __forceinline__ bool aabb_hit(cdp bb, V3 o, V3 d) {
+    double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
+    check_axis(o.x, d.x, bb[0], bb[3], AABB_EPS, xtmin, xtmax);
+    check_axis(o.y, d.y, bb[1], bb[4], AABB_EPS, ytmin, ytmax);
+    check_axis(o.z, d.z, bb[2], bb[5], AABB_EPS, ztmin, ztmax);
+    double tmin = fmax(fmax(xtmin, ytmin), ztmin);
+    double tmax = fmin(fmin(xtmax, ytmax), ztmax);
+    return tmin <= tmax;
+}
+
+// geometry/sphere.rs:51-74
+__device__ __forceinline__ bool hit_sphere(V3 o, V3 d, int leaf, Best &best) {
+    double a = dot(d, d);
+    double b = 2.0 * dot(d, o);
+    double c = dot(o, o) - 1.0;
+    double disc = b * b - 4.0 * a * c;
+    if (disc < 0.0) return false;
+    double sq = sqrt(disc);
+    double den = 2.0 * a;
+    cand((-b - sq) / den, leaf, best);
+    cand((-b + sq) / den, leaf, best);
+    return true;
+}
+
+// geometry/planes.rs:46-56
+__device__ __forceinline__ bool hit_plane(V3 o, V3 d, int leaf, Best &best) {
+    if (fabs(d.y) < EPS) return false;
+    cand(-o.y / d.y, leaf, best);
+    return true;
+}
+
+// geometry/cubes.rs:63-86
+__device__ __forceinline__ bool hit_cube(V3 o, V3 d, int leaf, Best &best) {
+    double tmin, tmax, ytmin, ytmax, ztmin, ztmax;
+    check_axis(o.x, d.x, -1.0, 1.0, EPS, tmin, tmax);
+    check_axis(o.y, d.y, -1.0, 1.0, EPS, ytmin, ytmax);
+    tmin = fmax(tmin, ytmin);
+    tmax = fmin(tmax, ytmax);
+    if (tmin > tmax) return false;
+    check_axis(o.z, d.z, -1.0, 1.0, EPS, ztmin, ztmax);
+    tmin = fmax(tmin, ztmin);
+    tmax = fmin(tmax, ztmax);
+    if (tmin > tmax) return false;
+    cand(tmin, leaf, best);
+    cand(tmax, leaf, best);
+    return true;
+}
+
+// geometry/cylinders.rs:124-144 (radius 1) and geometry/cones.rs:140-161 (radius |y|)
+template <bool CONE>
+__device__ __forceinline__ bool hit_caps(V3 o, V3 d, double minimum, double maximum, int closed, int leaf,
+                                         Best &best) {
+    if (!closed || fabs(d.y - 0.0) < EPS) return false;
+    bool any = false;
+    {
+        double t = (minimum - o.y) / d.y;
+        double x = o.x + t * d.x;
+        double z = o.z + t * d.z;
+        double r = CONE ? fabs(minimum) : 1.0;
+        double r2 = CONE ? r * r : 1.0;
+        if ((x * x + z * z) <= r2) {
+            cand(t, leaf, best);
+            any = true;
+        }
+    }
+    {
+        double t = (maximum - o.y) / d.y;
+        double x = o.x + t * d.x;
+        double z = o.z + t * d.z;
+        double r = CONE ? fabs(maximum) : 1.0;
+        double r2 = CONE ? r * r : 1.0;
+        if ((x * x + z * z) <= r2) {
+            cand(t, leaf, best);
+            any = true;
+        }
+    }
+    return any;
+}
+
+// geometry/cylinders.rs:57-99
+__device__ __forceinline__ bool hit_cylinder(V3 o, V3 d, double minimum, double maximum, int closed, int leaf,
+                                             Best &best) {
+    double a = d.x * d.x + d.z * d.z;
+    if (fabs(a - 0.0) < EPS) return hit_caps<false>(o, d, minimum, maximum, closed, leaf, best);
+    double b = 2.0 * o.x * d.x + 2.0 * o.z * d.z;
+    double c = o.x * o.x + o.z * o.z - 1.0;
+    double disc = b * b - 4.0 * a * c;
+    if (disc < 0.0) return false;  // no cap test on this branch (cylinders.rs:73-75)
+    double sq = sqrt(disc);
+    double den = 2.0 * a;
+    double t0 = (-b - sq) / den;
+    double t1 = (-b + sq) / den;
+    if (t0 > t1) {
+        double tmp = t0;
+        t0 = t1;
+        t1 = tmp;
+    }
+    bool any = false;
+    double y0 = o.y + t0 * d.y;
+    double y1 = o.y + t1 * d.y;
+    if (minimum < y0 && y0 < maximum) {
+        cand(t0, leaf, best);
+        any = true;
+    }
+    if (minimum < y1 && y1 < maximum) {
+        cand(t1, leaf, best);
+        any = true;
+    }
+    bool caps = hit_caps<false>(o, d, minimum, maximum, closed, leaf, best);
+    return any || caps;
+}
+
+// geometry/cones.rs:57-107
+__device__ __forceinline__ bool hit_cone(V3 o, V3 d, double minimum, double maximum, int closed, int leaf,
+                                         Best &best) {
+    double a = d.x * d.x - d.y * d.y + d.z * d.z;
+    double b = 2.0 * o.x * d.x - 2.0 * o.y * d.y + 2.0 * o.z * d.z;
+    double c = o.x * o.x - o.y * o.y + o.z * o.z;
+    bool any = false;
+    if (fabs(a - 0.0) < EPS) {
+        if (!(fabs(b - 0.0) < EPS)) {
+            double t = -c / (2.0 * b);
+            double y = o.y + t * d.y;
+            if (minimum < y && y < maximum) {
+                cand(t, leaf, best);
+                any = true;
+            }
+        }
+    } else {
+        double disc = b * b - 4.0 * a * c;
+        if (!(disc < 0.0)) {  // a negative discriminant still falls through to the caps (cones.rs:80-83)
+            double sq = sqrt(disc);
+            double den = 2.0 * a;
+            double t0 = (-b - sq) / den;
+            double t1 = (-b + sq) / den;
+            if (t0 > t1) {
+                double tmp = t0;
+                t0 = t1;
+                t1 = tmp;
+            }
+            double y0 = o.y + t0 * d.y;
+            if (minimum < y0 && y0 < maximum) {
+                cand(t0, leaf, best);
+                any = true;
+            }
+            double y1 = o.y + t1 * d.y;
+            if (minimum < y1 && y1 < maximum) {
+                cand(t1, leaf, best);
+                any = true;
+            }
+        }
+    }
+    bool caps = hit_caps<true>(o, d, minimum, maximum, closed, leaf, best);
+    return any || caps;
+}
+
+// World::intersect / collect_intersections (rendering/world.rs:27-78) over the node range [begin,end) at nesting
+// level D, for the lanes with `active` set.  begin, end and the running index are wave-uniform.
+template <int D, bool STATS>
+__device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end, V3 o, V3 d, bool active, Best &best,
+                                            Ctr<STATS> &ctr) {
+    for (int i = begin; i < end;) {
+        NodeP n = S.nodes + i;
+        const int kind = n->kind;
+        if (kind == RT_GROUP) {
+            const int skip = n->skip;
+            if constexpr (D < RT_MAX_GROUP_NESTING) {
+                bool inside = false;
+                V3 lo = mk(0.0, 0.0, 0.0), ld = mk(0.0, 0.0, 0.0);
+                if (active) {
+                    lo = mul_point((cdp)n->inv, o);
+                    ld = mul_vector((cdp)n->inv, d);
+                    inside = aabb_hit((cdp)n->a, lo, ld);
+                    ctr.add(C_XFORM);
+                    ctr.add(C_AABB);
+                }
+                if (__ballot(inside) != 0ull) trace_range<D + 1, STATS>(S, i + 1, skip, lo, ld, inside, best, ctr);
+            }
+            i = skip;
+        } else {
+            if (active) {
+                V3 lo = mul_point((cdp)n->inv, o);
+                V3 ld = mul_vector((cdp)n->inv, d);
+                const int leaf = n->leaf;
+                bool any;
+                switch (kind) {
+                    case RT_SPHERE: any = hit_sphere(lo, ld, leaf, best); break;
+                    case RT_PLANE: any = hit_plane(lo, ld, leaf, best); break;
+                    case RT_CUBE: any = hit_cube(lo, ld, leaf, best); break;
+                    case RT_CYLINDER: any = hit_cylinder(lo, ld, n->a[0], n->a[1], n->closed, leaf, best); break;
+                    default: any = hit_cone(lo, ld, n->a[0], n->a[1], n->closed, leaf, best); break;
+                }
+                if (STATS) {
+                    ctr.add(C_XFORM);
+                    ctr.add(C_PRIM_TESTS + kind);
+                    if (any) ctr.add(C_PRIM_HITS + kind);
+                }
+            }
+            i = i + 1;
+        }
+    }
+}
+
+template <bool STATS>
+__device__ __forceinline__ Best trace(const SceneK &S, V3 o, V3 d, bool active, Ctr<STATS> &ctr) {
+    Best best;
+    best.t = 0.0;
+    best.leaf = -1;
+    if (STATS && active) ctr.add(C_RAYS);
+    trace_range<0, STATS>(S, 0, S.n_nodes, o, d, active, best, ctr);
+    return best;
+}
+
+// Shape::local_normal_at of the leaf kinds
+__device__ __forceinline__ V3 local_normal_at(int kind, double minimum, double maximum, V3 p) {
+    switch (kind) {
+        case RT_SPHERE:  // geometry/sphere.rs:77-80
+            return p;
+        case RT_PLANE:  // geometry/planes.rs:58-60
+            return mk(0.0, 1.0, 0.0);
+        case RT_CUBE: {  // geometry/cubes.rs:88-98
+            double maxc = fmax(fmax(fabs(p.x), fabs(p.y)), fabs(p.z));
+            if (fabs(maxc - fabs(p.x)) < EPS) return mk(p.x, 0.0, 0.0);
+            if (fabs(maxc - fabs(p.y)) < EPS) return mk(0.0, p.y, 0.0);
+            return mk(0.0, 0.0, p.z);
+        }
+        case RT_CYLINDER: {  // geometry/cylinders.rs:101-111
+            double dist = p.x * p.x + p.z * p.z;
+            if (dist < 1.0 && p.y >= maximum - EPS) return mk(0.0, 1.0, 0.0);
+            if (dist < 1.0 && p.y <= minimum + EPS) return mk(0.0, -1.0, 0.0);
+            return mk(p.x, 0.0, p.z);
+        }
+        default: {  // geometry/cones.rs:109-126
+            double dist = p.x * p.x + p.z * p.z;
+            if (dist < 1.0 && p.y >= maximum - EPS) return mk(0.0, 1.0, 0.0);
+            if (dist < 1.0 && p.y <= minimum + EPS) return mk(0.0, -1.0, 0.0);
+            double y = sqrt(p.x * p.x + p.z * p.z);
+            if (p.y > 0.0) y = -y;
+            return mk(p.x, y, p.z);
+        }
+    }
+}
+
+// Object::normal_at (rendering/objects.rs:171-184)
+__device__ __forceinline__ V3 normal_at(const RtSurface *s, V3 world_point) {
+    V3 lp = mul_point(s->inv_world, world_point);
+    V3 ln = local_normal_at(s->kind, s->minimum, s->maximum, lp);
+    V3 wn = mul_vector_transposed(s->inv_world, ln);
+    return wn / magnitude(wn);
+}
+
+// Pattern::color_at (scene/patterns.rs:81-135); `%` on f64 is fmod, `as i32` saturates (v_cvt_i32_f64 does too)
+__device__ __forceinline__ V3 pattern_color(const RtSurface *s, V3 p) {
+    V3 a = mk(s->pat_a[0], s->pat_a[1], s->pat_a[2]);
+    V3 b = mk(s->pat_b[0], s->pat_b[1], s->pat_b[2]);
+    switch (s->pattern_kind) {
+        case RT_PATTERN_STRIPE:
+            return (fmod(floor(p.x), 2.0) == 0.0) ? a : b;
+        case RT_PATTERN_GRADIENT: {
+            V3 distance = b - a;
+            double f = p.x;
+            if (f < 0.0) f = 0.0; else if (f > 1.0) f = 1.0;
+            return a + distance * f;
+        }
+        case RT_PATTERN_RING:
+            return (fmod(floor(sqrt(p.x * p.x + p.z * p.z)), 2.0) == 0.0) ? a : b;
+        default: {
+            unsigned x = (unsigned)__double2int_rz(floor(p.x + CHECKER_EPS));
+            unsigned y = (unsigned)__double2int_rz(floor(p.y + CHECKER_EPS));
+            unsigned z = (unsigned)__double2int_rz(floor(p.z + CHECKER_EPS));
+            return (((x + y + z) & 1u) == 0u) ? a : b;
+        }
+    }
+}
+
+// Material::lighting (scene/materials.rs:122-172) with Pattern::color_at_object (scene/patterns.rs:137-146)
+template <bool STATS>
+__device__ __forceinline__ V3 lighting(const RtSurface *s, const RtLight &light, V3 point, V3 eye, V3 normal,
+                                       bool in_shadow, Ctr<STATS> &ctr) {
+    V3 color;
+    if (s->pattern_kind != RT_PATTERN_NONE) {
+        V3 object_point = mul_point(s->inv_world, point);
+        V3 pattern_point = mul_point(s->pat_inv, object_point);
+        color = pattern_color(s, pattern_point);
+        ctr.add(C_PATTERNS);
+    } else {
+        color = mk(s->color[0], s->color[1], s->color[2]);
+    }
+    V3 li = mk(light.intensity[0], light.intensity[1], light.intensity[2]);
+    V3 lp = mk(light.position[0], light.position[1], light.position[2]);
+    V3 effective = mk(color.x * li.x, color.y * li.y, color.z * li.z);
+    V3 lv = lp - point;
+    lv = lv / magnitude(lv);
+    V3 ambient = effective * s->ambient;
+    double ldn = dot(lv, normal);
+    V3 diffuse = mk(0.0, 0.0, 0.0), specular = mk(0.0, 0.0, 0.0);
+    if (ldn >= 0.0 && !in_shadow) {
+        ctr.add(C_LIT);
+        diffuse = (effective * s->diffuse) * ldn;
+        V3 rv = reflect(-lv, normal);
+        double rde = dot(rv, eye);
+        if (rde > 0.0) {
+            ctr.add(C_SPECULAR);
+            double factor = pow(rde, s->shininess);
+            specular = (li * s->specular) * factor;
+        }
+    }
+    return (ambient + diffuse) + specular;
+}
+
+// Camera::ray_for_pixel (rendering/camera.rs:39-54) with the inverse of the view transform precomputed
+__device__ __forceinline__ void ray_for_pixel(const RtCameraDev &cam, unsigned px, unsigned py, V3 &origin, V3 &dir) {
+    double xo = ((double)px + 0.5) * cam.pixel_size;
+    double yo = ((double)py + 0.5) * cam.pixel_size;
+    double wx = cam.half_width - xo;
+    double wy = cam.half_height - yo;
+    V3 pixel = mul_point(cam.inv, mk(wx, wy, -1.0));
+    origin = mk(cam.origin[0], cam.origin[1], cam.origin[2]);
+    V3 v = pixel - origin;
+    dir = v / magnitude(v);
+}
+
+enum { MODE_IDLE = 0, MODE_RADIANCE = 1, MODE_SHADOW = 2 };
+
+// World::color_at (rendering/world.rs:113-126) for one ray per lane.  Returns the colour in `acc`.
+//
+// The reference's recursion  color = surface + reflected*k_r + refracted*k_t  (world.rs:101-110, with
+// reflected = child*reflectivity, world.rs:167, and the Schlick factors when both are positive) is evaluated as a
+// sum over the nodes of the ray tree of  weight(node) * surface(node), weight being the product of the factors on
+// the path from the root.  That differs from the nested form only by floating-point reassociation (a few ulp).
+template <bool STATS>
+__device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 rd, int remaining0, V3 &acc,
+                                         Ctr<STATS> &ctr) {
+    int mode = valid ? MODE_RADIANCE : MODE_IDLE;
+    double w = 1.0;
+    int remaining = remaining0;
+    acc = mk(0.0, 0.0, 0.0);
+
+    // the hit being shaded while its shadow ray is in flight
+    V3 h_point = mk(0, 0, 0), h_normal = mk(0, 0, 0), h_dir = mk(0, 0, 0);
+    double h_dist = 0.0, h_t = 0.0;
+    int h_leaf = -1;
+
+    // parked refraction rays: origin, direction, weight; remaining budget
+    double stk[STACK_MAX][7];
+    int stk_rem[STACK_MAX];
+    int sp = 0;
+
+    const V3 light_pos = mk(S.light.position[0], S.light.position[1], S.light.position[2]);
+
+    while (__ballot(mode != MODE_IDLE) != 0ull) {
+        Best best = trace<STATS>(S, ro, rd, mode != MODE_IDLE, ctr);
+        bool need_next = false;
+        if (mode == MODE_RADIANCE) {
+            if (best.leaf >= 0 && S.light.has_light) {
+                // Intersection::prepare_computations (rendering/intersections.rs:45-63)
+                const RtSurface *s = S.surfaces + best.leaf;
+                V3 point = ro + rd * best.t;
+                V3 normal = normal_at(s, point);
+                V3 eye = -rd;
+                if (dot(normal, eye) < 0.0) normal = -normal;
+                V3 over = point + normal * EPS;
+                // World::is_shadowed (rendering/world.rs:128-141)
+                V3 v = light_pos - over;
+                double distance = magnitude(v);
+                h_point = point;
+                h_normal = normal;
+                h_dir = rd;
+                h_dist = distance;
+                h_t = best.t;
+                h_leaf = best.leaf;
+                ro = over;
+                rd = v / distance;
+                mode = MODE_SHADOW;
+                ctr.add(C_SHADES);
+                ctr.add(C_SHADOW);
+            } else {
+                need_next = true;  // miss (world.rs:124), or no light source (world.rs:86-89): black
+            }
+        } else if (mode == MODE_SHADOW) {
+            const RtSurface *s = S.surfaces + h_leaf;
+            bool in_shadow = best.leaf >= 0 && best.t < h_dist;  // world.rs:145-148
+            V3 eye = -h_dir;
+            V3 surface = lighting<STATS>(s, S.light, h_point, eye, h_normal, in_shadow, ctr);
+            acc = acc + surface * w;
+
+            const double reflectivity = s->reflectivity;
+            const double transparency = s->transparency;
+            bool do_reflect = remaining != 0 && reflectivity != 0.0;   // world.rs:156-162
+            bool do_refract = remaining != 0 && transparency != 0.0;   // world.rs:175-181
+            double cos_i = dot(eye, h_normal);
+            // n1/n2 as Intersection::prepare_computations leaves them when handed the one-element list [self]
+            // (intersections.rs:41-43,66-103): n1 = 1.0, n2 = the hit object's refractive index; a non-finite t
+            // fails float_equal(t, t) and leaves both at 1.0.
+            const double n1 = 1.0;
+            const double n2 = (fabs(h_t - h_t) < EPS) ? s->refractive_index : 1.0;
+            V3 refr_dir = mk(0.0, 0.0, 0.0);
+            if (do_refract) {  // world.rs:183-194
+                ctr.add(C_REFRACT_SETUPS);
+                double n_ratio = n1 / n2;
+                double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+                if (sin2_t > 1.0) {
+                    do_refract = false;
+                } else {
+                    double cos_t = sqrt(1.0 - sin2_t);
+                    refr_dir = h_normal * (n_ratio * cos_i - cos_t) - eye * n_ratio;
+                }
+            }
+            double w_reflect = w * reflectivity;
+            double w_refract = w * transparency;
+            if (reflectivity > 0.0 && transparency > 0.0) {  // world.rs:105-108, intersections.rs:123-136
+                ctr.add(C_SCHLICK);
+                double c = cos_i;
+                double reflectance;
+                bool total = false;
+                if (n1 > n2) {
+                    double n = n1 / n2;
+                    double sin2_t = (n * n) * (1.0 - c * c);
+                    if (sin2_t > 1.0) total = true;
+                    c = sqrt(1.0 - sin2_t);
+                }
+                if (total) {
+                    reflectance = 1.0;
+                } else {
+                    double q = (n1 - n2) / (n1 + n2);
+                    double r0 = q * q;
+                    double m = 1.0 - c;
+                    double m2 = m * m;
+                    double m5 = m * (m2 * m2);  // powi(5)
+                    reflectance = r0 + (1.0 - r0) * m5;
+                }
+                w_reflect = w_reflect * reflectance;
+                w_refract = w_refract * (1.0 - reflectance);
+            }
+            const int child_remaining = remaining - 1;
+            if (do_refract) ctr.add(C_REFRACT);
+            if (do_reflect) {
+                ctr.add(C_REFLECT);
+                if (do_refract) {  // park the refraction ray: under_point, direction (intersections.rs:63, world.rs:194)
+                    V3 under = h_point - h_normal * EPS;
+                    stk[sp][0] = under.x; stk[sp][1] = under.y; stk[sp][2] = under.z;
+                    stk[sp][3] = refr_dir.x; stk[sp][4] = refr_dir.y; stk[sp][5] = refr_dir.z;
+                    stk[sp][6] = w_refract;
+                    stk_rem[sp] = child_remaining;
+                    sp++;
+                }
+                ro = h_point + h_normal * EPS;      // over_point (intersections.rs:62)
+                rd = reflect(h_dir, h_normal);      // reflect_vector (intersections.rs:60)
+                w = w_reflect;
+                remaining = child_remaining;
+                mode = MODE_RADIANCE;
+            } else if (do_refract) {
+                ro = h_point - h_normal * EPS;
+                rd = refr_dir;
+                w = w_refract;
+                remaining = child_remaining;
+                mode = MODE_RADIANCE;
+            } else {
+                need_next = true;
+            }
+        }
+        if (need_next) {
+            if (sp > 0) {
+                sp--;
+                ro = mk(stk[sp][0], stk[sp][1], stk[sp][2]);
+                rd = mk(stk[sp][3], stk[sp][4], stk[sp][5]);
+                w = stk[sp][6];
+                remaining = stk_rem[sp];
+                mode = MODE_RADIANCE;
+            } else {
+                mode = MODE_IDLE;
+            }
+        }
+    }
+}
+
+template <bool STATS>
+__device__ __forceinline__ void flush_counters(Ctr<STATS> &, unsigned long long *) {}
+template <>
+__device__ __forceinline__ void flush_counters<true>(Ctr<true> &ctr, unsigned long long *out) {
+    for (int i = 0; i < RT_NUM_COUNTERS; ++i) {
+        unsigned long long v = ctr.c[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(out + i, v);
+    }
+}
+
+__device__ __forceinline__ SceneK scene_k(const DeviceScene &d, int max_depth) {
+    SceneK S;
+    S.nodes = (NodeP)d.nodes;
+    S.surfaces = d.surfaces;
+    S.n_nodes = d.n_nodes;
+    S.max_depth = max_depth;
+    S.light = d.light;
+    return S;
+}
+
+// Camera::render (rendering/camera.rs:56-67) for rows [row_begin,row_end).  Workgroup = 16x16 pixels, wave = 8x8.
+template <bool STATS>
+__global__ __launch_bounds__(256) void render_kernel(DeviceScene scene, RtCameraDev cam, unsigned row_begin,
+                                                     unsigned row_end, int max_depth, double *__restrict__ rgb,
+                                                     unsigned long long *counters) {
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const unsigned y = row_begin + blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool valid = x < cam.hsize && y < row_end;
+    SceneK S = scene_k(scene, max_depth);
+    Ctr<STATS> ctr;
+    ctr.clear();
+    V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+    if (valid) {
+        ray_for_pixel(cam, x, y, ro, rd);
+        ctr.add(C_PRIMARY);
+    }
+    V3 acc;
+    radiance<STATS>(S, valid, ro, rd, max_depth, acc, ctr);
+    if (valid) {
+        size_t idx = ((size_t)(y - row_begin) * cam.hsize + x) * 3;  // Canvas index (rendering/canvas.rs:40-42)
+        rgb[idx] = acc.x;
+        rgb[idx + 1] = acc.y;
+        rgb[idx + 2] = acc.z;
+    }
+    flush_counters<STATS>(ctr, counters);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void color_at_kernel(DeviceScene scene, const double *__restrict__ rays, unsigned n,
+                                                       int remaining, double *__restrict__ colors,
+                                                       unsigned long long *counters) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    SceneK S = scene_k(scene, remaining);
+    Ctr<STATS> ctr;
+    ctr.clear();
+    V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+    if (valid) {
+        ro = mk(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]);
+        rd = mk(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+    }
+    V3 acc;
+    radiance<STATS>(S, valid, ro, rd, remaining, acc, ctr);
+    if (valid) {
+        colors[i * 3 + 0] = acc.x;
+        colors[i * 3 + 1] = acc.y;
+        colors[i * 3 + 2] = acc.z;
+    }
+    flush_counters<STATS>(ctr, counters);
+}
+
+__global__ __launch_bounds__(256) void intersect_kernel(DeviceScene scene, const double *__restrict__ rays, unsigned n,
+                                                        double *__restrict__ t, int *__restrict__ object) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    SceneK S = scene_k(scene, 0);
+    Ctr<false> ctr;
+    V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+    if (valid) {
+        ro = mk(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]);
+        rd = mk(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+    }
+    Best best = trace<false>(S, ro, rd, valid, ctr);
+    if (valid) {
+        t[i] = best.leaf >= 0 ? best.t : __builtin_nan("");
+        object[i] = best.leaf >= 0 ? S.surfaces[best.leaf].object : -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void is_shadowed_kernel(DeviceScene scene, const double *__restrict__ points,
+                                                          unsigned n, uint8_t *__restrict__ out) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    SceneK S = scene_k(scene, 0);
+    Ctr<false> ctr;
+    V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+    double distance = 0.0;
+    const bool lit_world = S.light.has_light != 0;
+    if (valid) {
+        ro = mk(points[i * 3 + 0], points[i * 3 + 1], points[i * 3 + 2]);
+        V3 v = mk(S.light.position[0], S.light.position[1], S.light.position[2]) - ro;  // world.rs:136-138
+        distance = magnitude(v);
+        rd = v / distance;
+    }
+    Best best = trace<false>(S, ro, rd, valid && lit_world, ctr);
+    if (valid) out[i] = (lit_world && best.leaf >= 0 && best.t < distance) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void normal_at_kernel(DeviceScene scene, const int *__restrict__ leaf,
+                                                        const double *__restrict__ points, unsigned n,
+                                                        double *__restrict__ normals) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int l = leaf[i];
+    V3 r = mk(__builtin_nan(""), __builtin_nan(""), __builtin_nan(""));
+    if (l >= 0 && l < scene.n_leaves)
+        r = normal_at(scene.surfaces + l, mk(points[i * 3 + 0], points[i * 3 + 1], points[i * 3 + 2]));
+    normals[i * 3 + 0] = r.x;
+    normals[i * 3 + 1] = r.y;
+    normals[i * 3 + 2] = r.z;
+}
+
+__global__ __launch_bounds__(256) void ray_for_pixel_kernel(RtCameraDev cam, const unsigned *__restrict__ px,
+                                                            const unsigned *__restrict__ py, unsigned n,
+                                                            double *__restrict__ rays) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o, d;
+    ray_for_pixel(cam, px[i], py[i], o, d);
+    rays[i * 6 + 0] = o.x; rays[i * 6 + 1] = o.y; rays[i * 6 + 2] = o.z;
+    rays[i * 6 + 3] = d.x; rays[i * 6 + 4] = d.y; rays[i * 6 + 5] = d.z;
+}
+
+inline unsigned blocks_for(unsigned n) { return (n + 255u) / 256u; }
+
+}  // namespace
+
+hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, uint32_t row_begin, uint32_t row_end,
+                         int max_depth, double *rgb, unsigned long long *counters, hipStream_t stream) {
+    if (row_end <= row_begin || camera.hsize == 0) return hipSuccess;
+    dim3 grid((camera.hsize + 15) / 16, (row_end - row_begin + 15) / 16);
+    if (counters)
+        render_kernel<true><<<grid, 256, 0, stream>>>(scene, camera, row_begin, row_end, max_depth, rgb, counters);
+    else
+        render_kernel<false><<<grid, 256, 0, stream>>>(scene, camera, row_begin, row_end, max_depth, rgb, nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_color_at(const DeviceScene &scene, const double *rays, uint32_t n, int remaining, double *colors,
+                           unsigned long long *counters, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (counters)
+        color_at_kernel<true><<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, remaining, colors, counters);
+    else
+        color_at_kernel<false><<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, remaining, colors, nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_intersect(const DeviceScene &scene, const double *rays, uint32_t n, double *t, int32_t *object,
+                            hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    intersect_kernel<<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, t, object);
+    return hipGetLastError();
+}
+
+hipError_t launch_is_shadowed(const DeviceScene &scene, const double *points, uint32_t n, uint8_t *out,
+                              hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    is_shadowed_kernel<<<blocks_for(n), 256, 0, stream>>>(scene, points, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_normal_at(const DeviceScene &scene, const int32_t *leaf, const double *points, uint32_t n,
+                            double *normals, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    normal_at_kernel<<<blocks_for(n), 256, 0, stream>>>(scene, leaf, points, n, normals);
+    return hipGetLastError();
+}
+
+hipError_t launch_ray_for_pixel(const RtCameraDev &camera, const uint32_t *px, const uint32_t *py, uint32_t n,
+                                double *rays, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    ray_for_pixel_kernel<<<blocks_for(n), 256, 0, stream>>>(camera, px, py, n, rays);
+    return hipGetLastError();
+}
+
+}  // namespace rt

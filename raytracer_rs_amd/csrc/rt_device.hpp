@@ -1,0 +1,40 @@
+// Launchers of the gfx950 kernels (implemented in rt_device.hip).  Host code calls these; all pointers are device
+// pointers on the current HIP device, all launches are asynchronous on `stream`.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "rt_device_types.h"
+
+namespace rt {
+
+struct DeviceScene {
+    const RtNode *nodes = nullptr;
+    const RtSurface *surfaces = nullptr;
+    int32_t n_nodes = 0;
+    int32_t n_leaves = 0;
+    RtLight light{};
+};
+
+// Camera::render over rows [row_begin,row_end): rgb receives (row_end-row_begin)*hsize*3 doubles.
+// counters == nullptr launches the plain kernel; otherwise the counting variant adds into counters[RT_NUM_COUNTERS].
+hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, uint32_t row_begin, uint32_t row_end,
+                         int max_depth, double *rgb, unsigned long long *counters, hipStream_t stream);
+// World::color_at for n rays.
+hipError_t launch_color_at(const DeviceScene &scene, const double *rays, uint32_t n, int remaining, double *colors,
+                           unsigned long long *counters, hipStream_t stream);
+// World::intersect + Intersection::hit for n rays.
+hipError_t launch_intersect(const DeviceScene &scene, const double *rays, uint32_t n, double *t, int32_t *object,
+                            hipStream_t stream);
+// World::is_shadowed for n points.
+hipError_t launch_is_shadowed(const DeviceScene &scene, const double *points, uint32_t n, uint8_t *out,
+                              hipStream_t stream);
+// Object::normal_at for n (leaf, point) pairs; leaf indexes RtSurface[].
+hipError_t launch_normal_at(const DeviceScene &scene, const int32_t *leaf, const double *points, uint32_t n,
+                            double *normals, hipStream_t stream);
+// Camera::ray_for_pixel for n pixels.
+hipError_t launch_ray_for_pixel(const RtCameraDev &camera, const uint32_t *px, const uint32_t *py, uint32_t n,
+                                double *rays, hipStream_t stream);
+
+}  // namespace rt

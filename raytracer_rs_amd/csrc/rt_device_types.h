@@ -1,0 +1,61 @@
+// Plain-old-data tables the device kernels read; built on the host by rt_flatten.cpp.
+//
+// HBM layout (all read-only during a render):
+//   RtNode[n_nodes]       one per object, depth-first pre-order (= the reference's visiting order,
+//                         rendering/world.rs:29-32,66-68).  A group's subtree is nodes (i, skip); its children are at
+//                         nesting depth + 1.  Every node carries rows 0..2 of the inverse of its LOCAL
+//                         transformation: rays are taken down the hierarchy one local inverse at a time, as
+//                         World::collect_intersections / Object::intersect do (world.rs:53-58, objects.rs:121-126).
+//                         The node index is wave-uniform during traversal, so these are scalar loads.
+//   RtSurface[n_leaves]   one per leaf: rows 0..2 of the inverse of the cached WORLD transformation (normals and
+//                         patterns use that one, objects.rs:87-105) plus material and pattern.  Read per lane, only
+//                         for the object a ray actually hit.
+#pragma once
+
+#include <stdint.h>
+
+struct RtNode {
+    double inv[12];   // rows 0..2 of inverse(transformation), row-major 3x4
+    double a[6];      // group: bounds min.xyz, max.xyz (in the group's own space); leaf: a[0]=minimum, a[1]=maximum
+    int32_t kind;     // RT_SPHERE .. RT_GROUP
+    int32_t skip;     // index of the first node after this node's subtree
+    int32_t closed;   // cylinder / cone caps
+    int32_t leaf;     // index into RtSurface[], -1 for groups
+    int32_t object;   // index into rt_world_desc.objects
+    int32_t _pad[3];
+};
+
+struct RtSurface {
+    double inv_world[12];  // rows 0..2 of inverse(world_transformation)
+    double color[3];
+    double ambient, diffuse, specular, shininess, reflectivity, transparency, refractive_index;
+    double minimum, maximum;
+    double pat_inv[12];    // rows 0..2 of inverse(pattern.transform)
+    double pat_a[3], pat_b[3];
+    int32_t kind;
+    int32_t pattern_kind;  // RT_PATTERN_*
+    int32_t object;
+    int32_t _pad;
+};
+
+struct RtLight {
+    double position[3];
+    double intensity[3];
+    int32_t has_light;
+    int32_t _pad;
+};
+
+struct RtCameraDev {
+    double inv[12];     // rows 0..2 of inverse(camera.transform)
+    double origin[3];   // inverse * Point(0,0,0), the same for every pixel (rendering/camera.rs:51)
+    double half_width, half_height, pixel_size;
+    uint32_t hsize, vsize;
+};
+
+// Per-call counters; field order matches rt_stats (minus kernel_ms).
+struct RtCounters {
+    unsigned long long rays, primary, shadow, reflect, refract;
+    unsigned long long prim_tests[5], prim_hits[5];
+    unsigned long long aabb_tests, ray_transforms, shades, lit, specular, patterns, refract_setups, schlick;
+};
+#define RT_NUM_COUNTERS 23

@@ -1,0 +1,25 @@
+// World description -> flat device tables (host side, once per scene).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "../../include/raytracer_rs_amd.h"
+#include "rt_device_types.h"
+
+namespace rt {
+
+struct FlatScene {
+    std::vector<RtNode> nodes;
+    std::vector<RtSurface> surfaces;
+    RtLight light{};
+    uint32_t n_groups = 0;
+    uint32_t n_leaves = 0;
+    uint32_t max_nesting = 0;  // deepest nesting level of any node (top-level objects are level 0)
+};
+
+// Returns RT_OK or an RT_ERR_* code with a message in err.
+int flatten_world(const rt_world_desc &world, FlatScene &out, std::string &err);
+int camera_to_device(const rt_camera_desc &camera, RtCameraDev &out, std::string &err);
+
+}  // namespace rt
