@@ -116,6 +116,11 @@ typedef struct rt_render_opts {
     int32_t max_depth;           /* recursion budget per pixel; 0 = RT_DEFAULT_DEPTH */
     int32_t collect_stats;       /* non-zero: run the counting variant of the kernel and fill rt_stats */
     void *stream;                /* hipStream_t for rt_render_device; NULL = the null stream */
+    /* Row-band sharding (one frame over several GPUs): when band_rows > 0 the frame is cut into bands of band_rows
+     * rows and this call renders bands band_first, band_first + band_step, band_first + 2*band_step, ...
+     * (row_begin/row_end are ignored).  band_rows = 0 renders the contiguous range above. */
+    uint32_t band_rows, band_first, band_step;
+    uint32_t _pad;
 } rt_render_opts;
 
 typedef struct rt_scene_info {
@@ -145,8 +150,10 @@ int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
  * `rgb` (which holds the WHOLE frame: hsize*vsize*3 doubles; rows outside the range are left untouched). */
 int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts, double *rgb,
               rt_stats *stats);
-/* The same on device memory, asynchronously on opts->stream: `rgb_device` receives only the rows rendered,
- * (row_end-row_begin)*hsize*3 doubles starting at row_begin.  No host synchronisation unless collect_stats is set. */
+/* The same on device memory, asynchronously on opts->stream: `rgb_device` receives only the rows rendered, packed:
+ * (row_end-row_begin)*hsize*3 doubles starting at row_begin, or with bands the selected bands one after another
+ * (band_rows*hsize*3 doubles each, the frame's last band possibly shorter).  No host synchronisation unless
+ * collect_stats is set. */
 int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
                      double *rgb_device, rt_stats *stats);
 

@@ -17,6 +17,8 @@ from typing import Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+C = C  # re-exported for tests that build ctypes arrays
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "librt_oracle.so")
 

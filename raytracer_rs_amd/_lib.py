@@ -77,7 +77,8 @@ class Stats(C.Structure):
 
 class RenderOpts(C.Structure):
     _fields_ = [("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("max_depth", C.c_int32),
-                ("collect_stats", C.c_int32), ("stream", C.c_void_p)]
+                ("collect_stats", C.c_int32), ("stream", C.c_void_p), ("band_rows", C.c_uint32),
+                ("band_first", C.c_uint32), ("band_step", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class SceneInfo(C.Structure):

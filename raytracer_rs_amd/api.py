@@ -297,12 +297,16 @@ class Scene:
         return i
 
     def render(self, camera: "Camera", rows: Optional[Tuple[int, int]] = None, max_depth: int = 0,
-               stats: bool = False, out: Optional[np.ndarray] = None):
-        """rt_render into a host array [vsize, hsize, 3]; returns (array, Stats)."""
+               stats: bool = False, out: Optional[np.ndarray] = None,
+               bands: Optional[Tuple[int, int, int]] = None):
+        """rt_render into a host array [vsize, hsize, 3]; returns (array, Stats).  `rows` = (begin, end) restricts
+        the call to a row range, `bands` = (band_rows, first, step) to every step-th band of band_rows rows."""
         cd = camera._desc()
         if out is None:
             out = np.zeros((camera.vsize, camera.hsize, 3), dtype=np.float64)
         opts = L.RenderOpts()
+        if bands is not None:
+            opts.band_rows, opts.band_first, opts.band_step = bands
         if rows is not None:
             opts.row_begin, opts.row_end = rows
         opts.max_depth = max_depth
@@ -320,6 +324,20 @@ class Scene:
         opts = L.RenderOpts()
         if rows is not None:
             opts.row_begin, opts.row_end = rows
+        opts.max_depth = max_depth
+        opts.collect_stats = int(stats)
+        opts.stream = C.c_void_p(stream)
+        st = L.Stats()
+        L.check(L.lib().rt_render_device(self._h, C.byref(cd), C.byref(opts), C.c_void_p(device_ptr), C.byref(st)))
+        return st if stats else None
+
+    def render_device_bands(self, camera: "Camera", device_ptr: int, band_rows: int, band_first: int, band_step: int,
+                            max_depth: int = 0, stream: int = 0, stats: bool = False) -> Optional[L.Stats]:
+        """rt_render_device restricted to bands band_first, band_first+band_step, ... of band_rows rows each; the
+        bands are written one after another at `device_ptr`."""
+        cd = camera._desc()
+        opts = L.RenderOpts()
+        opts.band_rows, opts.band_first, opts.band_step = band_rows, band_first, band_step
         opts.max_depth = max_depth
         opts.collect_stats = int(stats)
         opts.stream = C.c_void_p(stream)

@@ -88,24 +88,46 @@ int clamp_depth(int d) {
     return d > RT_MAX_DEPTH ? RT_MAX_DEPTH : d;
 }
 
-int render_rows(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts, uint32_t &row_begin,
-                uint32_t &row_end, int &depth, RtCameraDev &cam) {
+// Validates a render call and works out which rows it covers.
+int render_rows(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts, rt::RowMap &rows,
+                int &depth, RtCameraDev &cam) {
     if (!scene || !camera) return set_error(RT_ERR_INVALID_ARGUMENT, "scene and camera must not be NULL");
     if (camera->hsize == 0 || camera->vsize == 0) return set_error(RT_ERR_INVALID_ARGUMENT, "camera has zero size");
-    row_begin = 0;
-    row_end = camera->vsize;
+    uint32_t row_begin = 0, row_end = camera->vsize;
     depth = RT_DEFAULT_DEPTH;
+    rows = rt::RowMap{};
     if (opts) {
-        if (opts->row_begin || opts->row_end) {
-            row_begin = opts->row_begin;
-            row_end = opts->row_end;
-        }
         if (opts->max_depth < 0 || opts->max_depth > RT_MAX_DEPTH)
             return set_error(RT_ERR_INVALID_ARGUMENT, "max_depth must be within 0.." + std::to_string(RT_MAX_DEPTH));
         depth = clamp_depth(opts->max_depth);
+        if (opts->band_rows) {
+            if (opts->band_step == 0) return set_error(RT_ERR_INVALID_ARGUMENT, "band_step must be positive");
+            const uint32_t n_bands = (camera->vsize + opts->band_rows - 1) / opts->band_rows;
+            uint32_t mine = opts->band_first < n_bands ? (n_bands - opts->band_first + opts->band_step - 1) / opts->band_step : 0;
+            rows.band_rows = opts->band_rows;
+            rows.band_pitch = opts->band_step * opts->band_rows;
+            rows.row_begin = opts->band_first * opts->band_rows;
+            rows.row_end = camera->vsize;
+            rows.n_rows = 0;
+            if (mine) {
+                uint32_t last_start = (opts->band_first + (mine - 1) * opts->band_step) * opts->band_rows;
+                uint32_t last_len = camera->vsize - last_start < opts->band_rows ? camera->vsize - last_start : opts->band_rows;
+                rows.n_rows = (mine - 1) * opts->band_rows + last_len;
+            }
+        } else if (opts->row_begin || opts->row_end) {
+            row_begin = opts->row_begin;
+            row_end = opts->row_end;
+        }
     }
-    if (row_begin > row_end || row_end > camera->vsize)
-        return set_error(RT_ERR_INVALID_ARGUMENT, "row range lies outside the frame");
+    if (!(opts && opts->band_rows)) {
+        if (row_begin > row_end || row_end > camera->vsize)
+            return set_error(RT_ERR_INVALID_ARGUMENT, "row range lies outside the frame");
+        rows.row_begin = row_begin;
+        rows.row_end = row_end;
+        rows.n_rows = row_end - row_begin;
+        rows.band_rows = rows.n_rows ? rows.n_rows : 1;
+        rows.band_pitch = 0;
+    }
     std::string err;
     int rc = rt::camera_to_device(*camera, cam, err);
     if (rc != RT_OK) return set_error(rc, err);
@@ -198,12 +220,12 @@ int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out) {
 
 int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
                      double *rgb_device, rt_stats *stats) {
-    uint32_t r0, r1;
+    rt::RowMap rows;
     int depth;
     RtCameraDev cam;
-    int rc = render_rows(scene, camera, opts, r0, r1, depth, cam);
+    int rc = render_rows(scene, camera, opts, rows, depth, cam);
     if (rc != RT_OK) return rc;
-    if (!rgb_device && r1 > r0) return set_error(RT_ERR_INVALID_ARGUMENT, "rgb_device must not be NULL");
+    if (!rgb_device && rows.n_rows) return set_error(RT_ERR_INVALID_ARGUMENT, "rgb_device must not be NULL");
     const bool want_stats = opts && opts->collect_stats;
     if (want_stats && !stats) return set_error(RT_ERR_INVALID_ARGUMENT, "collect_stats needs a stats pointer");
     hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
@@ -211,7 +233,7 @@ int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const 
     if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (want_stats) HIP_TRY(hipMemsetAsync(scene->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), stream));
-    HIP_TRY(rt::launch_render(scene->dev, cam, r0, r1, depth, rgb_device, want_stats ? scene->d_counters : nullptr, stream));
+    HIP_TRY(rt::launch_render(scene->dev, cam, rows, depth, rgb_device, want_stats ? scene->d_counters : nullptr, stream));
     if (want_stats) {
         unsigned long long c[RT_NUM_COUNTERS];
         HIP_TRY(hipMemcpyAsync(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
@@ -223,19 +245,20 @@ int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const 
 
 int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts, double *rgb,
               rt_stats *stats) {
-    uint32_t r0, r1;
+    rt::RowMap rows;
     int depth;
     RtCameraDev cam;
-    int rc = render_rows(scene, camera, opts, r0, r1, depth, cam);
+    int rc = render_rows(scene, camera, opts, rows, depth, cam);
     if (rc != RT_OK) return rc;
     if (!rgb) return set_error(RT_ERR_INVALID_ARGUMENT, "rgb must not be NULL");
     if (stats) std::memset(stats, 0, sizeof *stats);
-    if (r1 == r0) return RT_OK;
+    if (rows.n_rows == 0) return RT_OK;
     const bool want_stats = opts && opts->collect_stats;
     if (want_stats && !stats) return set_error(RT_ERR_INVALID_ARGUMENT, "collect_stats needs a stats pointer");
     DeviceGuard guard(scene->device);
     if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
-    const size_t count = (size_t)(r1 - r0) * camera->hsize * 3;
+    const size_t row_vals = (size_t)camera->hsize * 3;
+    const size_t count = (size_t)rows.n_rows * row_vals;
     DeviceBuffer<double> buf;
     HIP_TRY(buf.alloc(count));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -243,9 +266,15 @@ int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_rend
     hipError_t e = hipEventCreate(&ev1);
     if (e == hipSuccess && want_stats) e = hipMemsetAsync(scene->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), nullptr);
     if (e == hipSuccess) e = hipEventRecord(ev0, nullptr);
-    if (e == hipSuccess) e = rt::launch_render(scene->dev, cam, r0, r1, depth, buf.p, want_stats ? scene->d_counters : nullptr, nullptr);
+    if (e == hipSuccess) e = rt::launch_render(scene->dev, cam, rows, depth, buf.p, want_stats ? scene->d_counters : nullptr, nullptr);
     if (e == hipSuccess) e = hipEventRecord(ev1, nullptr);
-    if (e == hipSuccess) e = hipMemcpy(rgb + (size_t)r0 * camera->hsize * 3, buf.p, count * sizeof(double), hipMemcpyDeviceToHost);
+    // packed rows -> their place in the caller's whole-frame buffer, one copy per band
+    for (uint32_t r = 0; e == hipSuccess && r < rows.n_rows; r += rows.band_rows) {
+        uint32_t y = rows.row_begin + (r / rows.band_rows) * rows.band_pitch;
+        uint32_t len = rows.n_rows - r < rows.band_rows ? rows.n_rows - r : rows.band_rows;
+        e = hipMemcpy(rgb + (size_t)y * row_vals, buf.p + (size_t)r * row_vals, (size_t)len * row_vals * sizeof(double),
+                      hipMemcpyDeviceToHost);
+    }
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
     unsigned long long c[RT_NUM_COUNTERS];

@@ -633,15 +633,15 @@ __device__ __forceinline__ SceneK scene_k(const DeviceScene &d, int max_depth) {
     return S;
 }
 
-// Camera::render (rendering/camera.rs:56-67) for rows [row_begin,row_end).  Workgroup = 16x16 pixels, wave = 8x8.
+// Camera::render (rendering/camera.rs:56-67) for the rows of `rows`.  Workgroup = 16x16 pixels, wave = 8x8.
 template <bool STATS>
-__global__ __launch_bounds__(256) void render_kernel(DeviceScene scene, RtCameraDev cam, unsigned row_begin,
-                                                     unsigned row_end, int max_depth, double *__restrict__ rgb,
-                                                     unsigned long long *counters) {
+__global__ __launch_bounds__(256) void render_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth,
+                                                     double *__restrict__ rgb, unsigned long long *counters) {
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const unsigned y = row_begin + blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool valid = x < cam.hsize && y < row_end;
+    const unsigned r = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);  // row in the packed output
+    const unsigned y = rows.row_begin + (r / rows.band_rows) * rows.band_pitch + (r % rows.band_rows);
+    const bool valid = x < cam.hsize && r < rows.n_rows && y < rows.row_end;
     SceneK S = scene_k(scene, max_depth);
     Ctr<STATS> ctr;
     ctr.clear();
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void render_kernel(DeviceScene scene, RtCamera
     V3 acc;
     radiance<STATS>(S, valid, ro, rd, max_depth, acc, ctr);
     if (valid) {
-        size_t idx = ((size_t)(y - row_begin) * cam.hsize + x) * 3;  // Canvas index (rendering/canvas.rs:40-42)
+        size_t idx = ((size_t)r * cam.hsize + x) * 3;  // Canvas index (rendering/canvas.rs:40-42) within the rows rendered
         rgb[idx] = acc.x;
         rgb[idx + 1] = acc.y;
         rgb[idx + 2] = acc.z;
@@ -751,14 +751,14 @@ inline unsigned blocks_for(unsigned n) { return (n + 255u) / 256u; }
 
 }  // namespace
 
-hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, uint32_t row_begin, uint32_t row_end,
-                         int max_depth, double *rgb, unsigned long long *counters, hipStream_t stream) {
-    if (row_end <= row_begin || camera.hsize == 0) return hipSuccess;
-    dim3 grid((camera.hsize + 15) / 16, (row_end - row_begin + 15) / 16);
+hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows, int max_depth,
+                         double *rgb, unsigned long long *counters, hipStream_t stream) {
+    if (rows.n_rows == 0 || camera.hsize == 0 || rows.band_rows == 0) return hipSuccess;
+    dim3 grid((camera.hsize + 15) / 16, (rows.n_rows + 15) / 16);
     if (counters)
-        render_kernel<true><<<grid, 256, 0, stream>>>(scene, camera, row_begin, row_end, max_depth, rgb, counters);
+        render_kernel<true><<<grid, 256, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters);
     else
-        render_kernel<false><<<grid, 256, 0, stream>>>(scene, camera, row_begin, row_end, max_depth, rgb, nullptr);
+        render_kernel<false><<<grid, 256, 0, stream>>>(scene, camera, rows, max_depth, rgb, nullptr);
     return hipGetLastError();
 }
 

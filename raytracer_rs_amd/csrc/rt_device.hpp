@@ -17,10 +17,19 @@ struct DeviceScene {
     RtLight light{};
 };
 
-// Camera::render over rows [row_begin,row_end): rgb receives (row_end-row_begin)*hsize*3 doubles.
+// Which rows of the frame one launch renders, and where they land in the packed output buffer: packed row r
+// (0 <= r < n_rows) is frame row  row_begin + (r / band_rows) * band_pitch + (r % band_rows), rendered only when
+// that is < row_end.  A contiguous range is band_rows = n_rows, band_pitch = 0.
+struct RowMap {
+    uint32_t row_begin = 0, row_end = 0;
+    uint32_t n_rows = 0;
+    uint32_t band_rows = 1, band_pitch = 0;
+};
+
+// Camera::render over the rows of `rows`: rgb receives n_rows*hsize*3 doubles.
 // counters == nullptr launches the plain kernel; otherwise the counting variant adds into counters[RT_NUM_COUNTERS].
-hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, uint32_t row_begin, uint32_t row_end,
-                         int max_depth, double *rgb, unsigned long long *counters, hipStream_t stream);
+hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows, int max_depth,
+                         double *rgb, unsigned long long *counters, hipStream_t stream);
 // World::color_at for n rays.
 hipError_t launch_color_at(const DeviceScene &scene, const double *rays, uint32_t n, int remaining, double *colors,
                            unsigned long long *counters, hipStream_t stream);

@@ -1,0 +1,363 @@
+"""Parity of the HIP renderer with the CPU oracle, through the C ABI (all tests need an MI355X).
+
+The bar (stated once, used everywhere below):
+  * f64 colours within TOL = 1e-6 of the oracle before quantisation;
+  * 8-bit images within +-1 level on >= 99.9 % of pixels;
+  * everything that is an index, a count or a decision is exact: hit object indices, ray/operation counters,
+    shadow flags, and intersection distances t (same IEEE operations in the same order, no contraction).
+The only arithmetic that is not bit-identical to the oracle is `powf` in the specular term (device libm vs glibc)
+and the summation order of the ray tree (path weights instead of nested sums), both a few ulp; GUARD = 1e-12 is a
+regression tripwire far below TOL that any real divergence (a flipped decision, a wrong epsilon) breaks.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, scene_path
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+GUARD = 1e-12
+S2 = math.sqrt(2.0)
+ALL_SCENES = ["chapter_5", "chapter_6", "chapter_7_and_8", "chapter_9", "chapter_10", "chapter_11", "chapter_12",
+              "chapter_13", "chapter_14"]
+PPM_PAIRS = [("chapter_5", "chapter_5_circle"), ("chapter_6", "chapter_6_sphere"), ("chapter_10", "chapter_10_patterns"),
+             ("chapter_11", "chapter_11_reflections"), ("chapter_13", "chapter_13_rocket")]
+
+
+def assert_frames_match(orc, gpu_img, ref_img):
+    d = np.abs(gpu_img - ref_img)
+    assert d.max() <= TOL, f"max |gpu - oracle| = {d.max()}"
+    assert d.max() <= GUARD, f"max |gpu - oracle| = {d.max()} (within the 1e-6 bar but beyond the expected few ulp)"
+    qg, qr = orc.quantize(gpu_img).astype(int), orc.quantize(ref_img).astype(int)
+    off = np.abs(qg - qr).max(axis=2)
+    assert (off <= 1).mean() >= 0.999
+    assert (off > 0).mean() <= 1e-4
+
+
+def counters_equal(stats, counters):
+    assert stats.as_dict() == counters.as_dict()
+
+
+def load_both(rt, orc, scene, width=None, height=None):
+    sf = rt.SceneFile.from_file(scene_path(scene))
+    cam = sf.build_camera(width, height)
+    world = sf.build_world()
+    ocam, oworld = orc.load_scene(scene_path(scene), width, height)
+    return cam, world, ocam, oworld
+
+
+@pytest.mark.parametrize("scene", ALL_SCENES)
+def test_scene_matches_oracle(gpu, rt, orc, scene):
+    cam, world, ocam, oworld = load_both(rt, orc, scene)
+    img, st = world.scene().render(cam, stats=True)
+    oc = orc.Counters()
+    ref = orc.render(ocam, oworld, threads=16, counters=oc)
+    assert_frames_match(orc, img, ref)
+    counters_equal(st, oc)
+    plain, _ = world.scene().render(cam)
+    assert np.array_equal(plain, img), "counting and plain kernels disagree"
+
+
+@pytest.mark.parametrize("scene,image", PPM_PAIRS)
+def test_gpu_reproduces_reference_ppm(gpu, rt, scene, image):
+    """Straight against the reference's own renderings: Camera::render -> Canvas::to_ppm."""
+    import hashlib
+    import json
+
+    sf = rt.SceneFile.from_file(scene_path(scene))
+    canvas = sf.build_camera().render(sf.build_world())
+    golden = np.load(os.path.join(GOLDEN, image + ".npz"))["pixels"].astype(int)
+    off = np.abs(canvas.to_rgb8().astype(int) - golden).max(axis=2)
+    assert (off <= 1).mean() >= 0.999
+    assert off.max() == 0, f"{int((off > 0).sum())} pixels differ from the reference PPM"
+    with open(os.path.join(GOLDEN, "MANIFEST.json")) as f:
+        sha = json.load(f)["ppm"][image]["sha256_p3_text"]
+    assert hashlib.sha256(canvas.to_ppm_string()).hexdigest() == sha
+
+
+# --------------------------------------------------------------------------- the reference's unit tests, on the GPU
+def close(a, b, eps=1e-5):
+    return all(abs(x - y) < eps for x, y in zip(a, b))
+
+
+def test_world_known_answers(gpu, rt):
+    w = rt.World.default()
+    r = rt.Ray((0, 0, -5), (0, 0, 1))
+    assert w.hit(r) == (4.0, 0)  # world.rs:265-274: first of 4, 4.5, 5.5, 6
+    assert w.color_at(rt.Ray((0, 0, -5), (0, 1, 0))) == (0.0, 0.0, 0.0)  # world.rs:308-313
+    assert close(w.color_at(r), (0.38066, 0.47583, 0.2855))  # world.rs:316-321
+    inner = rt.World.default()
+    inner.light_source = rt.PointLight((0, 0.25, 0), (1, 1, 1))
+    # world.rs:291-305 through color_at: from inside the inner sphere
+    assert close(inner.color_at(rt.Ray((0, 0, 0), (0, 0, 1))), (0.90498, 0.90498, 0.90498))
+    amb = rt.World.default()
+    amb.objects[0].material.ambient = 1.0
+    amb.objects[1].material.ambient = 1.0
+    assert close(amb.color_at(rt.Ray((0, 0, 0.75), (0, 0, -1))), amb.objects[1].material.color)  # world.rs:324-346
+    assert not w.is_shadowed((0, 10, 0))  # world.rs:349-374
+    assert w.is_shadowed((10, -10, 10))
+    assert not w.is_shadowed((-20, 20, -20))
+    assert not w.is_shadowed((-2, 2, -2))
+    sh = rt.World()
+    sh.light_source = rt.PointLight((0, 0, -10), (1, 1, 1))
+    sh.objects = [rt.Object.sphere(), rt.Object.sphere(transformation=rt.Matrix4.translate(0, 0, 10))]
+    assert close(sh.color_at(rt.Ray((0, 0, 5), (0, 0, 1))), (0.1, 0.1, 0.1))  # world.rs:377-393
+    assert rt.World().color_at(r) == (0.0, 0.0, 0.0)  # empty world (world.rs:251-255)
+    dark = rt.World.default()
+    dark.light_source = None
+    assert dark.color_at(r) == (0.0, 0.0, 0.0)  # no light: black (world.rs:86-89)
+
+
+def test_reflection_refraction_known_answers(gpu, rt, orc):
+    def floor_world(**mat):
+        w = rt.World.default()
+        w.objects.append(rt.Object.plane(transformation=rt.Matrix4.translate(0, -1, 0), material=rt.Material(**mat)))
+        return w
+
+    r = rt.Ray((0, 0, -3), (0, -S2 / 2, S2 / 2))
+    assert close(floor_world(reflectivity=0.5).color_at(r), (0.87676, 0.92434, 0.82917))  # world.rs:440-470
+    # depth 0: the reflective floor is lit but casts no further ray (world.rs:502-524)
+    w = floor_world(reflectivity=0.5)
+    c0, st = w.scene().color_at(np.array([[0, 0, -3, 0, -S2 / 2, S2 / 2]]), remaining=0, stats=True)
+    assert st.reflect == 0 and st.rays == 2
+    mirrors = rt.World()
+    mirrors.light_source = rt.PointLight((0, 0, 0), (1, 1, 1))
+    mirrors.objects = [rt.Object.plane(transformation=rt.Matrix4.translate(0, -1, 0), material=rt.Material(reflectivity=1.0)),
+                       rt.Object.plane(transformation=rt.Matrix4.translate(0, 1, 0), material=rt.Material(reflectivity=1.0))]
+    _, st = mirrors.scene().color_at(np.array([[0, 0, 0, 0, 1, 0]]), stats=True)  # world.rs:474-499: terminates
+    assert st.reflect == 5
+    ball = rt.Object.sphere(transformation=rt.Matrix4.translate(0, -3.5, -0.5), material=rt.Material(color=(1, 0, 0), ambient=0.5))
+    w = floor_world(transparency=0.5, refractive_index=1.5)
+    w.objects.append(ball)
+    assert close(w.color_at(r), (0.93642, 0.68642, 0.68642))  # world.rs:651-695
+    w = floor_world(reflectivity=0.5, transparency=0.5, refractive_index=1.5)
+    w.objects.append(ball)
+    assert close(w.color_at(r), (0.93391, 0.69643, 0.69243))  # world.rs:698-744
+
+
+def test_camera_known_answers(gpu, rt):
+    cam = rt.Camera(201, 101, math.pi / 2)
+    r = cam.ray_for_pixel(100, 50)  # camera.rs:106-111
+    assert r.origin == (0, 0, 0) and close(r.direction, (0, 0, -1))
+    r = cam.ray_for_pixel(0, 0)  # camera.rs:114-122
+    assert close(r.direction, (0.6651864261194508, 0.3325932130597254, -0.6685123582500481), 1e-15)
+    cam.transform = rt.Matrix4.rotate_y(math.pi / 4) * rt.Matrix4.translate(0, -2, 5)
+    r = cam.ray_for_pixel(100, 50)  # camera.rs:125-134
+    assert close(r.origin, (0, 2, -5)) and close(r.direction, (S2 / 2, 0, -S2 / 2))
+    cam = rt.Camera(11, 11, math.pi / 2)
+    cam.transform = rt.view_transform((0, 0, -5), (0, 0, 0), (0, 1, 0))
+    image = cam.render(rt.World.default())  # camera.rs:137-147
+    assert close(image.pixel_at(5, 5), (0.38066, 0.47583, 0.2855))
+    bad = rt.Camera(4, 4, 1.0)
+    bad.transform = rt.Matrix4.scale(1, 0, 1)
+    with pytest.raises(rt.RtError) as e:  # camera.rs:46-49 panics; here an error code
+        bad.render(rt.World.default())
+    assert e.value.code == -2 and "camera transform should be invertible" in e.value.message
+
+
+def test_camera_rays_match_oracle_exactly(gpu, rt, orc):
+    sf = rt.SceneFile.from_file(scene_path("chapter_14"))
+    cam = sf.build_camera()
+    ocam, _ = orc.load_scene(scene_path("chapter_14"))
+    rng = np.random.default_rng(3)
+    px = rng.integers(0, cam.hsize, 200).tolist() + [0, cam.hsize - 1]
+    py = rng.integers(0, cam.vsize, 200).tolist() + [0, cam.vsize - 1]
+    for ray, x, y in zip(cam.rays_for_pixels(px, py), px, py):
+        o = orc.ray_for_pixel(ocam, x, y)
+        assert ray.origin == o.origin.tuple() and ray.direction == o.direction.tuple()
+
+
+def test_group_known_answers(gpu, rt):
+    w = rt.World()
+    g = rt.Object.group()
+    s1, s2, s3 = rt.Object.sphere(), rt.Object.sphere(transformation=rt.Matrix4.translate(0, 0, -3)), \
+        rt.Object.sphere(transformation=rt.Matrix4.translate(5, 0, 0))
+    for s in (s1, s2, s3):
+        g.add_child(s)
+    w.objects = [g]
+    t, obj = w.hit(rt.Ray((0, 0, -5), (0, 0, 1)))  # groups.rs:244-273: 1, 3 (s2), 4, 6 (s1)
+    assert t == 1.0 and obj == w.object_index(s2)
+    assert w.hit(rt.Ray((10, 10, 10), (1, 0, 0))) is None  # groups.rs:452-469
+    w = rt.World()
+    g = rt.Object.group(transformation=rt.Matrix4.scale(2, 2, 2))
+    g.add_child(rt.Object.sphere(transformation=rt.Matrix4.translate(5, 0, 0)))
+    w.objects = [g]
+    assert w.hit(rt.Ray((10, 0, -10), (0, 0, 1))) is not None  # groups.rs:276-293
+    w = rt.World()
+    g1 = rt.Object.group(transformation=rt.Matrix4.rotate_y(math.pi / 2))
+    g2 = rt.Object.group(transformation=rt.Matrix4.scale(1, 2, 3))
+    s = rt.Object.sphere(transformation=rt.Matrix4.translate(5, 0, 0))
+    g2.add_child(s)
+    g1.add_child(g2)
+    w.objects = [g1]
+    n = w.scene().normal_at([w.object_index(s)], np.array([[1.7321, 1.1547, -5.5774]]))[0]  # groups.rs:351-376
+    assert close(n, (0.2857, 0.4286, -0.8571), 1e-4)
+    with pytest.raises(rt.RtError):  # groups.rs:125-127: groups have no normal
+        w.scene().normal_at([w.object_index(g1)], np.array([[0.0, 0.0, 0.0]]))
+
+
+# --------------------------------------------------------------------------- shapes: exact t and hit object
+def _single_object_worlds(rt, orc):
+    I = None
+    cases = []
+    spec = [
+        (rt.SPHERE, orc.SPHERE, {}), (rt.PLANE, orc.PLANE, {}), (rt.CUBE, orc.CUBE, {}),
+        (rt.CYLINDER, orc.CYLINDER, {}), (rt.CYLINDER, orc.CYLINDER, dict(minimum=1.0, maximum=2.0)),
+        (rt.CYLINDER, orc.CYLINDER, dict(minimum=-0.5, maximum=0.75, closed=True)),
+        (rt.CONE, orc.CONE, {}), (rt.CONE, orc.CONE, dict(minimum=-0.5, maximum=0.5, closed=True)),
+        (rt.CONE, orc.CONE, dict(minimum=-1.0, maximum=0.0, closed=True)),
+    ]
+    transforms = [None, (("translate", (0.3, -0.2, 0.5)), ("rotate_x", 0.7), ("scale", (0.8, 1.3, 0.6)))]
+    for kind, okind, kw in spec:
+        for tr in transforms:
+            m, om = rt.Matrix4.identity(), orc.identity()
+            if tr:
+                for name, arg in tr:
+                    a = arg if isinstance(arg, tuple) else (arg,)
+                    m = m * getattr(rt.Matrix4, name)(*a)
+                    om = orc.mul(om, getattr(orc, name)(*a))
+            w = rt.World()
+            w.light_source = rt.PointLight((-10, 10, -10), (1, 1, 1))
+            w.objects = [rt.Object(kind, m, None, kw.get("minimum", -math.inf), kw.get("maximum", math.inf), kw.get("closed", False))]
+            ow = orc.World()
+            ow.set_light((-10, 10, -10), (1, 1, 1))
+            ow.add(okind, om, None, -1, kw.get("minimum", -math.inf), kw.get("maximum", math.inf), kw.get("closed", False))
+            cases.append((w, ow))
+    return cases
+
+
+def test_intersections_are_bit_exact(gpu, rt, orc):
+    rng = np.random.default_rng(11)
+    n = 4000
+    origins = rng.uniform(-3, 3, size=(n, 3))
+    targets = rng.uniform(-1.2, 1.2, size=(n, 3))
+    dirs = targets - origins
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    # axis-parallel, tangent and cap-grazing rays: the branches the thresholds guard
+    special = np.array([[0, 0, -5, 0, 0, 1], [0, 1, -5, 0, 0, 1], [1, 0, -5, 0, 0, 1], [0, 0, -1, 0, S2 / 2, S2 / 2],
+                        [0, 0, -0.25, 0, 1, 0], [0, 3, 0, 0, -1, 0], [0.5, 5, 0, 0, -1, 0], [2, 2, 0, -1, 0, 0],
+                        [0, 1, 0, 1, 0, 0], [0, 1e-6, -2, 0, 0, 1], [0, 0.5, 0, 1, 1e-6, 0], [0, 0, 0, 0, 0, 1]], dtype=float)
+    rays = np.concatenate([np.concatenate([origins, dirs], axis=1), special])
+    for w, ow in _single_object_worlds(rt, orc):
+        t, obj = w.scene().intersect(rays)
+        for i, ray in enumerate(rays):
+            hit = ow.hit(orc.ray(ray[:3], ray[3:]))
+            if hit is None:
+                assert obj[i] == -1 and math.isnan(t[i]), (i, ray)
+            else:
+                assert obj[i] == hit[1] and t[i] == hit[0], (i, ray, t[i], hit)
+
+
+def test_normals_are_bit_exact(gpu, rt, orc):
+    rng = np.random.default_rng(5)
+    for w, ow in _single_object_worlds(rt, orc):
+        pts = rng.uniform(-1.5, 1.5, size=(300, 3))
+        got = w.scene().normal_at([0] * len(pts), pts)
+        for p, g in zip(pts, got):
+            e = ow.normal_at(0, p)
+            assert all((a == b) or (math.isnan(a) and math.isnan(b)) for a, b in zip(g, e)), (p, g, e)
+
+
+# --------------------------------------------------------------------------- generated scenes
+@pytest.mark.parametrize("seed", range(1, 13))
+def test_random_scene_matches_oracle(gpu, rt, orc, seed):
+    import tomli
+
+    from raytracer_rs_amd import synthetic
+
+    text = synthetic.random_scene(seed, 96, 64)
+    sf = rt.SceneFile.from_str(text)
+    cam, world = sf.build_camera(), sf.build_world()
+    ocam, oworld = orc.scene_from_dict(tomli.loads(text))
+    img, st = world.scene().render(cam, stats=True)
+    oc = orc.Counters()
+    ref = orc.render(ocam, oworld, threads=8, counters=oc)
+    assert_frames_match(orc, img, ref)
+    counters_equal(st, oc)
+
+
+def test_large_generated_scene_matches_oracle(gpu, rt, orc):
+    """The 10 000-leaf, three-level hierarchy at a reduced frame size."""
+    import tomli
+
+    from raytracer_rs_amd import synthetic
+
+    text = synthetic.large_scene(320, 180)
+    sf = rt.SceneFile.from_str(text)
+    cam, world = sf.build_camera(), sf.build_world()
+    info = world.scene().info()
+    assert (info.n_leaves, info.n_groups, info.max_nesting) == (10001, 500, 2)
+    ocam, oworld = orc.scene_from_dict(tomli.loads(text))
+    img, st = world.scene().render(cam, stats=True)
+    oc = orc.Counters()
+    ref = orc.render(ocam, oworld, threads=16, counters=oc)
+    assert_frames_match(orc, img, ref)
+    counters_equal(st, oc)
+
+
+# --------------------------------------------------------------------------- rows, bands, sizes, depth
+def test_row_ranges_and_bands_tile_the_frame(gpu, rt, orc):
+    cam, world, ocam, oworld = load_both(rt, orc, "chapter_11", 203, 77)
+    scene = world.scene()
+    full, st_full = scene.render(cam, stats=True)
+    assert_frames_match(orc, full, orc.render(ocam, oworld, threads=8))
+    part = np.full_like(full, -1.0)
+    scene.render(cam, rows=(10, 45), out=part)
+    assert np.array_equal(part[10:45], full[10:45]) and (part[:10] == -1).all() and (part[45:] == -1).all()
+    for band_rows, world_size in ((16, 2), (16, 8), (4, 3), (32, 5)):
+        acc = np.full_like(full, -1.0)
+        rays = 0
+        for r in range(world_size):
+            _, st = scene.render(cam, bands=(band_rows, r, world_size), out=acc, stats=True)
+            rays += st.rays
+        assert np.array_equal(acc, full)
+        assert rays == st_full.rays
+    with pytest.raises(rt.RtError):
+        scene.render(cam, rows=(50, 200))
+
+
+@pytest.mark.parametrize("size", [(1, 1), (17, 9), (33, 65), (64, 1), (1, 40), (250, 130)])
+def test_odd_frame_sizes(gpu, rt, orc, size):
+    cam, world, ocam, oworld = load_both(rt, orc, "chapter_13", *size)
+    img, st = world.scene().render(cam, stats=True)
+    oc = orc.Counters()
+    assert_frames_match(orc, img, orc.render(ocam, oworld, counters=oc))
+    counters_equal(st, oc)
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2, 3, 5, 7, 8])
+def test_recursion_budget(gpu, rt, orc, depth):
+    """World::color_at_internal(ray, remaining) for other budgets than the default 5 (world.rs:117)."""
+    cam, world, ocam, oworld = load_both(rt, orc, "chapter_11", 60, 45)
+    px = [x for y in range(45) for x in range(60)]
+    py = [y for y in range(45) for x in range(60)]
+    rays = np.array([list(r.origin) + list(r.direction) for r in cam.rays_for_pixels(px, py)])
+    got, st = world.scene().color_at(rays, remaining=depth, stats=True)
+    oc = orc.Counters()
+    ref = np.array([oworld.color_at(orc.ray(r[:3], r[3:]), depth, oc) for r in rays])
+    assert np.abs(got - ref).max() <= GUARD
+    assert st.rays == oc.rays and st.reflect == oc.reflect and st.refract == oc.refract
+
+
+# --------------------------------------------------------------------------- full size
+def test_full_4k_frame(gpu, rt, orc):
+    """The benchmark configuration itself: chapter_11 at 3840x2160, whole frame against the oracle, ray count exact,
+    two renders bit-identical, bands of 16 rows over 8 ranks reassemble the same frame."""
+    cam, world, ocam, oworld = load_both(rt, orc, "chapter_11", 3840, 2160)
+    scene = world.scene()
+    img, st = scene.render(cam, stats=True)
+    again, _ = scene.render(cam)
+    assert np.array_equal(img, again)
+    oc = orc.Counters()
+    ref = orc.render(ocam, oworld, threads=16, counters=oc)
+    assert_frames_match(orc, img, ref)
+    counters_equal(st, oc)
+    assert st.rays == st.primary + st.shadow + st.reflect + st.refract and st.primary == 3840 * 2160
+    acc = np.zeros_like(img)
+    for r in range(8):
+        scene.render(cam, bands=(16, r, 8), out=acc)
+    assert np.array_equal(acc, img)
