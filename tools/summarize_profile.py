@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Distils gpurun_out/prof_<tag>/ (written by tools/profile.sh) into profiles/<tag>_summary.md,
+profiles/<tag>_kernel_stats.csv and profiles/pmc_traffic.json.
+
+    python tools/summarize_profile.py <tag> [kernel substring]
+"""
+import csv
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main() -> None:
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    needle = sys.argv[2] if len(sys.argv) > 2 else "render_kernel<false>"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    lines = [f"# rocprofv3 summary `{tag}`", "",
+             "Command per pass: `rocprofv3 <pass args> --output-format csv -- python3 bench.py --no-cpu-baseline "
+             "--steps K --warmup W` (tools/profile.sh); kernel-trace pass K=20, counter passes K=3.", ""]
+
+    stats = os.path.join(src, "trace_kernel_stats.csv")
+    shutil.copyfile(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    lines += ["## Kernel time (`--kernel-trace --stats`)", "", "| kernel | calls | avg ms | min ms | max ms | % |", "|---|---|---|---|---|---|"]
+    avg_ms = None
+    with open(stats) as f:
+        for row in csv.DictReader(f):
+            name = row["Name"]
+            short = name.split("(")[0].replace("void rt::(anonymous namespace)::", "")
+            lines.append(f"| `{short}` | {row['Calls']} | {float(row['AverageNs']) / 1e6:.4f} | {float(row['MinNs']) / 1e6:.4f} | "
+                         f"{float(row['MaxNs']) / 1e6:.4f} | {float(row['Percentage']):.2f} |")
+            if needle in name:
+                avg_ms = float(row["AverageNs"]) / 1e6
+    with open(os.path.join(src, "trace.bench.json")) as f:
+        bench = json.loads(f.read().strip().splitlines()[-1])
+    lines += ["", f"bench.py in the same run: value {bench['value']} {bench['unit']}, ms_per_step {bench['ms_per_step']}, "
+                  f"roofline.kernel_ms {bench['roofline']['kernel_ms']} (rocprof average {avg_ms:.4f} ms).", ""]
+
+    with open(os.path.join(src, "trace_kernel_trace.csv")) as f:
+        for row in csv.DictReader(f):
+            if needle in row["Kernel_Name"]:
+                lines += [f"Dispatch of `{needle}`: grid {row['Grid_Size_X']}x{row['Grid_Size_Y']}, workgroup "
+                          f"{row['Workgroup_Size_X']}, VGPR {row['VGPR_Count']}, AGPR {row['Accum_VGPR_Count']}, SGPR {row['SGPR_Count']}, "
+                          f"scratch {row['Scratch_Size']} B/lane, LDS {row['LDS_Block_Size']} B.", ""]
+                break
+
+    counters = defaultdict(list)
+    for fn in sorted(os.listdir(src)):
+        if not fn.endswith("_counter_collection.csv"):
+            continue
+        with open(os.path.join(src, fn)) as f:
+            per_dispatch = defaultdict(dict)
+            for row in csv.DictReader(f):
+                if needle in row["Kernel_Name"]:
+                    per_dispatch[row["Dispatch_Id"]][row["Counter_Name"]] = per_dispatch[row["Dispatch_Id"]].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            for d in per_dispatch.values():
+                for k, v in d.items():
+                    counters[k].append(v)
+    mean = {k: sum(v) / len(v) for k, v in counters.items()}
+    lines += [f"## Counters, mean per launch of `{needle}` (`--pmc`, one pass per group)", "", "| counter | value |", "|---|---|"]
+    for k in sorted(mean):
+        lines.append(f"| {k} | {mean[k]:.6g} |")
+    lines.append("")
+    derived = []
+    if "SQ_THREAD_CYCLES_VALU" in mean and "SQ_ACTIVE_INST_VALU" in mean and mean["SQ_ACTIVE_INST_VALU"]:
+        # active lanes per VALU instruction-cycle: THREAD_CYCLES / (ACTIVE_INST_VALU * 4 [quad-cycles -> cycles]) / 64 ... reported as the gfx9 VALUUtilization formula
+        util = 100.0 * mean["SQ_THREAD_CYCLES_VALU"] / (mean["SQ_ACTIVE_INST_VALU"] * 64.0)
+        derived.append(f"VALU lane utilisation (SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64)) = {util:.1f} %")
+    if "SQ_ACTIVE_INST_VALU" in mean and "SQ_BUSY_CYCLES" in mean and mean["SQ_BUSY_CYCLES"]:
+        derived.append(f"SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = {mean['SQ_ACTIVE_INST_VALU'] / mean['SQ_WAVE_CYCLES']:.3f} "
+                       f"(share of wave lifetime spent issuing VALU)")
+    if "SQ_WAVE_CYCLES" in mean:
+        for k in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):
+            if k in mean:
+                derived.append(f"{k} / SQ_WAVE_CYCLES = {mean[k] / mean['SQ_WAVE_CYCLES']:.3f}")
+    f64 = [mean.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")]
+    if sum(f64):
+        derived.append(f"f64 VALU wave-instructions per launch: add {f64[0]:.4g}, mul {f64[1]:.4g}, fma {f64[2]:.4g}, trans {f64[3]:.4g}; "
+                       f"x64 lanes -> executed f64 flops (fma = 2) <= {(f64[0] + f64[1] + 2 * f64[2] + f64[3]) * 64:.4g}")
+    traffic = {}
+    if "FETCH_SIZE" in mean:
+        # FETCH_SIZE is in KiB-like units of 1024 B on this counter set?  rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KB.
+        traffic["fetch_kb_reported"] = mean["FETCH_SIZE"]
+    if "WRITE_SIZE" in mean:
+        traffic["write_kb_reported"] = mean["WRITE_SIZE"]
+    if traffic:
+        fetch_b = traffic.get("fetch_kb_reported", 0.0) * 1024.0
+        write_b = traffic.get("write_kb_reported", 0.0) * 1024.0
+        # MI355X guide: FETCH_SIZE reports half the bytes of wide coalesced streaming reads on gfx950 (double it);
+        # WRITE_SIZE is exact for 16-B-per-lane streaming stores; other widths uncalibrated.
+        traffic["hbm_bytes_per_launch"] = 2.0 * fetch_b + write_b
+        traffic["note"] = ("FETCH_SIZE (KB) x 1024 x 2 [gfx950 under-report of wide reads, per the MI355X guide] + WRITE_SIZE (KB) x 1024; "
+                           "the stores of this kernel are 8-B-per-lane strided, a width the guide marks uncalibrated")
+        derived.append(f"HBM traffic per launch ~ {traffic['hbm_bytes_per_launch'] / 1e6:.1f} MB "
+                       f"(fetch {2 * fetch_b / 1e6:.1f} MB corrected, write {write_b / 1e6:.1f} MB); the frame is 199.1 MB of stores")
+        with open(os.path.join(dst, "pmc_traffic.json"), "w") as f:
+            json.dump(traffic, f, indent=1)
+    lines += ["## Derived", ""] + [f"* {d}" for d in derived] + [""]
+    with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
+        f.write("\n".join(lines))
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
