@@ -175,7 +175,9 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
 
     size_t nb = sc->flat.nodes.size() * sizeof(RtNode), sb = sc->flat.surfaces.size() * sizeof(RtSurface);
-    HIP_TRY(hipMalloc((void **)&sc->d_nodes, nb ? nb : sizeof(RtNode)));
+    // one inert record past the end: the traversal prefetches node i+1 while it works on node i
+    HIP_TRY(hipMalloc((void **)&sc->d_nodes, nb + sizeof(RtNode)));
+    HIP_TRY(hipMemset((char *)sc->d_nodes + nb, 0, sizeof(RtNode)));
     e = hipMalloc((void **)&sc->d_surfaces, sb ? sb : sizeof(RtSurface));
     if (e == hipSuccess) e = hipMalloc((void **)&sc->d_counters, RT_NUM_COUNTERS * sizeof(unsigned long long));
     if (e == hipSuccess && nb) e = hipMemcpy(sc->d_nodes, sc->flat.nodes.data(), nb, hipMemcpyHostToDevice);
@@ -185,11 +187,12 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
         rt_scene_destroy(raw);
         return hip_error(e, "uploading the scene");
     }
-    sc->device_bytes = nb + sb + RT_NUM_COUNTERS * sizeof(unsigned long long);
+    sc->device_bytes = nb + sizeof(RtNode) + sb + RT_NUM_COUNTERS * sizeof(unsigned long long);
     sc->dev.nodes = sc->d_nodes;
     sc->dev.surfaces = sc->d_surfaces;
     sc->dev.n_nodes = (int32_t)sc->flat.nodes.size();
     sc->dev.n_leaves = (int32_t)sc->flat.surfaces.size();
+    sc->dev.max_nesting = (int32_t)sc->flat.max_nesting;
     sc->dev.light = sc->flat.light;
     *out = sc.release();
     return RT_OK;

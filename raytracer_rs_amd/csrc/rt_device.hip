@@ -20,6 +20,8 @@
 //     cache, the per-hit surface records through the vector L1.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "../../include/raytracer_rs_amd.h"
 #include "rt_device.hpp"
 
@@ -292,60 +294,137 @@ __device__ __forceinline__ bool hit_cone(V3 o, V3 d, double minimum, double maxi
     return any || caps;
 }
 
-// World::intersect / collect_intersections (rendering/world.rs:27-78) over the node range [begin,end) at nesting
-// level D, for the lanes with `active` set.  begin, end and the running index are wave-uniform.
-template <int D, bool STATS>
-__device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end, V3 o, V3 d, bool active, Best &best,
-                                            Ctr<STATS> &ctr) {
-    for (int i = begin; i < end;) {
-        NodeP n = S.nodes + i;
-        const int kind = n->kind;
-        if (kind == RT_GROUP) {
-            const int skip = n->skip;
-            if constexpr (D < RT_MAX_GROUP_NESTING) {
-                bool inside = false;
-                V3 lo = mk(0.0, 0.0, 0.0), ld = mk(0.0, 0.0, 0.0);
-                if (active) {
-                    lo = mul_point((cdp)n->inv, o);
-                    ld = mul_vector((cdp)n->inv, d);
-                    inside = aabb_hit((cdp)n->a, lo, ld);
-                    ctr.add(C_XFORM);
-                    ctr.add(C_AABB);
-                }
-                if (__ballot(inside) != 0ull) trace_range<D + 1, STATS>(S, i + 1, skip, lo, ld, inside, best, ctr);
-            }
-            i = skip;
-        } else {
-            if (active) {
-                V3 lo = mul_point((cdp)n->inv, o);
-                V3 ld = mul_vector((cdp)n->inv, d);
-                const int leaf = n->leaf;
-                bool any;
-                switch (kind) {
-                    case RT_SPHERE: any = hit_sphere(lo, ld, leaf, best); break;
-                    case RT_PLANE: any = hit_plane(lo, ld, leaf, best); break;
-                    case RT_CUBE: any = hit_cube(lo, ld, leaf, best); break;
-                    case RT_CYLINDER: any = hit_cylinder(lo, ld, n->a[0], n->a[1], n->closed, leaf, best); break;
-                    default: any = hit_cone(lo, ld, n->a[0], n->a[1], n->closed, leaf, best); break;
-                }
-                if (STATS) {
-                    ctr.add(C_XFORM);
-                    ctr.add(C_PRIM_TESTS + kind);
-                    if (any) ctr.add(C_PRIM_HITS + kind);
-                }
-            }
-            i = i + 1;
-        }
+// The per-node fields every traversal step needs, held in SGPRs (the node index is wave-uniform): the 3x4 inverse
+// matrix (24 dwords) and the four words after it (kind, xform, leaf, skip) -- the first 112 bytes of an RtNode,
+// fetched as three wide scalar loads.
+//
+// The loads are `volatile`: that pins them where they are written.  The traversal asks for node i+1 at the top of
+// the iteration that works on node i, and without the qualifier the optimiser sinks that request down to its first
+// use (the next iteration), which exposes the full scalar-cache latency once per node.  The compiler still tracks
+// the outstanding loads itself and places the s_waitcnt before the first use.
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct NodeRaw {
+    i32x16 a;  // inv[0..7]
+    i32x8 b;   // inv[8..11]
+    i32x4 c;   // kind, xform, leaf, skip
+};
+static_assert(offsetof(RtNode, kind) == 96 && offsetof(RtNode, skip) == 108, "RtNode hot fields moved");
+
+__device__ __forceinline__ NodeRaw node_fetch(NodeP n) {
+    const char RT_CONSTANT_AS *p = (const char RT_CONSTANT_AS *)n;
+    NodeRaw r;
+    r.a = *(const volatile i32x16 RT_CONSTANT_AS *)(p);
+    r.b = *(const volatile i32x8 RT_CONSTANT_AS *)(p + 64);
+    r.c = *(const volatile i32x4 RT_CONSTANT_AS *)(p + 96);
+    return r;
+}
+
+struct NodeRegs {
+    double m[12];
+    int kind, xform, leaf, skip;
+};
+__device__ __forceinline__ double dwords_to_double(int lo, int hi) {
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ NodeRegs node_regs(const NodeRaw &r) {
+    NodeRegs n;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) n.m[k] = dwords_to_double(r.a[2 * k], r.a[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) n.m[8 + k] = dwords_to_double(r.b[2 * k], r.b[2 * k + 1]);
+    // The loads are scalar (uniform address), but the optimiser treats the result of a volatile load as possibly
+    // divergent; say explicitly that the words steering the traversal are wave-uniform.
+    n.kind = __builtin_amdgcn_readfirstlane(r.c[0]);
+    n.xform = __builtin_amdgcn_readfirstlane(r.c[1]);
+    n.leaf = __builtin_amdgcn_readfirstlane(r.c[2]);
+    n.skip = __builtin_amdgcn_readfirstlane(r.c[3]);
+    return n;
+}
+
+// Ray::transform (rendering/rays.rs:22-24) by a node's inverse.  xform is wave-uniform, so this is a scalar branch:
+// a scale-and-translate inverse (every sphere of a typical scene) needs 9 operations instead of 33, an identity none.
+__device__ __forceinline__ void to_local(const NodeRegs &n, V3 o, V3 d, V3 &lo, V3 &ld) {
+    if (n.xform == RT_XFORM_IDENTITY) {
+        lo = o;
+        ld = d;
+    } else if (n.xform == RT_XFORM_DIAGONAL) {
+        lo = mk(n.m[0] * o.x + n.m[3], n.m[5] * o.y + n.m[7], n.m[10] * o.z + n.m[11]);
+        ld = mk(n.m[0] * d.x, n.m[5] * d.y, n.m[10] * d.z);
+    } else {
+        lo = mul_point(n.m, o);
+        ld = mul_vector(n.m, d);
     }
 }
 
-template <bool STATS>
+// World::intersect / collect_intersections (rendering/world.rs:27-78) over the node range [begin,end) at nesting
+// level D of a scene whose deepest level is NEST, for the lanes with `active` set.  begin, end and the running index
+// are wave-uniform.  The record of node i+1 is requested while node i is being worked on, so the scalar-cache
+// latency of one node hides behind the arithmetic of the previous one.
+template <int D, int NEST, bool STATS>
+__device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end, V3 o, V3 d, bool active, Best &best,
+                                            Ctr<STATS> &ctr) {
+    if (begin >= end) return;
+    NodeRaw raw = node_fetch(S.nodes + begin);
+    // Consume one word of the first record here, so that its arrival is awaited before the loop and not at the top
+    // of every iteration (where the wait would also cover the request for the following record).
+    asm volatile("" ::"s"(raw.c[0]));
+    int i = begin;
+    while (i < end) {
+        NodeP np = S.nodes + i;
+        const NodeRegs cur = node_regs(raw);
+        NodeRaw nraw = node_fetch(np + 1);  // in flight while this node is worked on (the table has one spare record)
+        int ni = i + 1;
+        if (D < NEST && cur.kind == RT_GROUP) {
+            if constexpr (D < NEST) {
+                bool inside = false;
+                V3 lo = mk(0.0, 0.0, 0.0), ld = mk(0.0, 0.0, 0.0);
+                if (active) {
+                    to_local(cur, o, d, lo, ld);
+                    inside = aabb_hit((cdp)np->a, lo, ld);
+                    ctr.add(C_XFORM);
+                    ctr.add(C_AABB);
+                }
+                if (__ballot(inside) != 0ull) trace_range<D + 1, NEST, STATS>(S, i + 1, cur.skip, lo, ld, inside, best, ctr);
+                ni = cur.skip;
+            }
+        } else if (cur.kind != RT_GROUP) {
+            if (active) {
+                V3 lo, ld;
+                to_local(cur, o, d, lo, ld);
+                bool any;
+                switch (cur.kind) {
+                    case RT_SPHERE: any = hit_sphere(lo, ld, cur.leaf, best); break;
+                    case RT_PLANE: any = hit_plane(lo, ld, cur.leaf, best); break;
+                    case RT_CUBE: any = hit_cube(lo, ld, cur.leaf, best); break;
+                    case RT_CYLINDER: any = hit_cylinder(lo, ld, np->a[0], np->a[1], np->closed, cur.leaf, best); break;
+                    default: any = hit_cone(lo, ld, np->a[0], np->a[1], np->closed, cur.leaf, best); break;
+                }
+                if (STATS) {
+                    ctr.add(C_XFORM);
+                    ctr.add(C_PRIM_TESTS + cur.kind);
+                    if (any) ctr.add(C_PRIM_HITS + cur.kind);
+                }
+            }
+        } else {
+            ni = cur.skip;  // a group at the deepest level the scene declares: it has no children
+        }
+        if constexpr (NEST > 0) {
+            if (ni != i + 1) nraw = node_fetch(S.nodes + ni);  // the subtree was stepped over: fetch the record wanted
+        }
+        raw = nraw;
+        i = __builtin_amdgcn_readfirstlane(ni);  // every operand above is wave-uniform; keep the index in an SGPR
+    }
+}
+
+template <int NEST, bool STATS>
 __device__ __forceinline__ Best trace(const SceneK &S, V3 o, V3 d, bool active, Ctr<STATS> &ctr) {
     Best best;
     best.t = 0.0;
     best.leaf = -1;
     if (STATS && active) ctr.add(C_RAYS);
-    trace_range<0, STATS>(S, 0, S.n_nodes, o, d, active, best, ctr);
+    trace_range<0, NEST, STATS>(S, 0, S.n_nodes, o, d, active, best, ctr);
     return best;
 }
 
@@ -466,7 +545,7 @@ enum { MODE_IDLE = 0, MODE_RADIANCE = 1, MODE_SHADOW = 2 };
 // reflected = child*reflectivity, world.rs:167, and the Schlick factors when both are positive) is evaluated as a
 // sum over the nodes of the ray tree of  weight(node) * surface(node), weight being the product of the factors on
 // the path from the root.  That differs from the nested form only by floating-point reassociation (a few ulp).
-template <bool STATS>
+template <int NEST, bool STATS>
 __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 rd, int remaining0, V3 &acc,
                                          Ctr<STATS> &ctr) {
     int mode = valid ? MODE_RADIANCE : MODE_IDLE;
@@ -487,7 +566,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
     const V3 light_pos = mk(S.light.position[0], S.light.position[1], S.light.position[2]);
 
     while (__ballot(mode != MODE_IDLE) != 0ull) {
-        Best best = trace<STATS>(S, ro, rd, mode != MODE_IDLE, ctr);
+        Best best = trace<NEST, STATS>(S, ro, rd, mode != MODE_IDLE, ctr);
         bool need_next = false;
         if (mode == MODE_RADIANCE) {
             if (best.leaf >= 0 && S.light.has_light) {
@@ -634,7 +713,7 @@ __device__ __forceinline__ SceneK scene_k(const DeviceScene &d, int max_depth) {
 }
 
 // Camera::render (rendering/camera.rs:56-67) for the rows of `rows`.  Workgroup = 16x16 pixels, wave = 8x8.
-template <bool STATS>
+template <bool STATS, int NEST>
 __global__ __launch_bounds__(256) void render_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth,
                                                      double *__restrict__ rgb, unsigned long long *counters) {
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -651,7 +730,7 @@ __global__ __launch_bounds__(256) void render_kernel(DeviceScene scene, RtCamera
         ctr.add(C_PRIMARY);
     }
     V3 acc;
-    radiance<STATS>(S, valid, ro, rd, max_depth, acc, ctr);
+    radiance<NEST, STATS>(S, valid, ro, rd, max_depth, acc, ctr);
     if (valid) {
         size_t idx = ((size_t)r * cam.hsize + x) * 3;  // Canvas index (rendering/canvas.rs:40-42) within the rows rendered
         rgb[idx] = acc.x;
@@ -661,7 +740,7 @@ __global__ __launch_bounds__(256) void render_kernel(DeviceScene scene, RtCamera
     flush_counters<STATS>(ctr, counters);
 }
 
-template <bool STATS>
+template <bool STATS, int NEST>
 __global__ __launch_bounds__(256) void color_at_kernel(DeviceScene scene, const double *__restrict__ rays, unsigned n,
                                                        int remaining, double *__restrict__ colors,
                                                        unsigned long long *counters) {
@@ -676,7 +755,7 @@ __global__ __launch_bounds__(256) void color_at_kernel(DeviceScene scene, const 
         rd = mk(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
     }
     V3 acc;
-    radiance<STATS>(S, valid, ro, rd, remaining, acc, ctr);
+    radiance<NEST, STATS>(S, valid, ro, rd, remaining, acc, ctr);
     if (valid) {
         colors[i * 3 + 0] = acc.x;
         colors[i * 3 + 1] = acc.y;
@@ -696,7 +775,7 @@ __global__ __launch_bounds__(256) void intersect_kernel(DeviceScene scene, const
         ro = mk(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]);
         rd = mk(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
     }
-    Best best = trace<false>(S, ro, rd, valid, ctr);
+    Best best = trace<RT_MAX_GROUP_NESTING, false>(S, ro, rd, valid, ctr);
     if (valid) {
         t[i] = best.leaf >= 0 ? best.t : __builtin_nan("");
         object[i] = best.leaf >= 0 ? S.surfaces[best.leaf].object : -1;
@@ -718,7 +797,7 @@ __global__ __launch_bounds__(256) void is_shadowed_kernel(DeviceScene scene, con
         distance = magnitude(v);
         rd = v / distance;
     }
-    Best best = trace<false>(S, ro, rd, valid && lit_world, ctr);
+    Best best = trace<RT_MAX_GROUP_NESTING, false>(S, ro, rd, valid && lit_world, ctr);
     if (valid) out[i] = (lit_world && best.leaf >= 0 && best.t < distance) ? 1 : 0;
 }
 
@@ -751,24 +830,41 @@ inline unsigned blocks_for(unsigned n) { return (n + 255u) / 256u; }
 
 }  // namespace
 
+// The kernels are compiled once per nesting depth of the scene (0 = no groups at all): registers for the rays of
+// levels a scene does not have are never allocated, and a flat scene carries no group code.
+template <bool STATS>
+static void launch_render_nest(int nest, dim3 grid, hipStream_t stream, const DeviceScene &scene, const RtCameraDev &camera,
+                               const RowMap &rows, int max_depth, double *rgb, unsigned long long *counters) {
+    switch (nest) {
+        case 0: render_kernel<STATS, 0><<<grid, 256, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
+        case 1: render_kernel<STATS, 1><<<grid, 256, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
+        case 2: render_kernel<STATS, 2><<<grid, 256, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
+        default: render_kernel<STATS, RT_MAX_GROUP_NESTING><<<grid, 256, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
+    }
+}
+
 hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows, int max_depth,
                          double *rgb, unsigned long long *counters, hipStream_t stream) {
     if (rows.n_rows == 0 || camera.hsize == 0 || rows.band_rows == 0) return hipSuccess;
     dim3 grid((camera.hsize + 15) / 16, (rows.n_rows + 15) / 16);
     if (counters)
-        render_kernel<true><<<grid, 256, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters);
+        launch_render_nest<true>(scene.max_nesting, grid, stream, scene, camera, rows, max_depth, rgb, counters);
     else
-        render_kernel<false><<<grid, 256, 0, stream>>>(scene, camera, rows, max_depth, rgb, nullptr);
+        launch_render_nest<false>(scene.max_nesting, grid, stream, scene, camera, rows, max_depth, rgb, nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_color_at(const DeviceScene &scene, const double *rays, uint32_t n, int remaining, double *colors,
                            unsigned long long *counters, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    if (counters)
-        color_at_kernel<true><<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, remaining, colors, counters);
-    else
-        color_at_kernel<false><<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, remaining, colors, nullptr);
+    const bool flat = scene.max_nesting == 0;
+    if (counters) {
+        if (flat) color_at_kernel<true, 0><<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, remaining, colors, counters);
+        else color_at_kernel<true, RT_MAX_GROUP_NESTING><<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, remaining, colors, counters);
+    } else {
+        if (flat) color_at_kernel<false, 0><<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, remaining, colors, nullptr);
+        else color_at_kernel<false, RT_MAX_GROUP_NESTING><<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, remaining, colors, nullptr);
+    }
     return hipGetLastError();
 }
 

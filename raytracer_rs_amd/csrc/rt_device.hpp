@@ -14,6 +14,8 @@ struct DeviceScene {
     const RtSurface *surfaces = nullptr;
     int32_t n_nodes = 0;
     int32_t n_leaves = 0;
+    int32_t max_nesting = 0;  // deepest nesting level of any node (0: no groups)
+    int32_t _pad = 0;
     RtLight light{};
 };
 

@@ -1,12 +1,14 @@
 // Plain-old-data tables the device kernels read; built on the host by rt_flatten.cpp.
 //
 // HBM layout (all read-only during a render):
-//   RtNode[n_nodes]       one per object, depth-first pre-order (= the reference's visiting order,
-//                         rendering/world.rs:29-32,66-68).  A group's subtree is nodes (i, skip); its children are at
+//   RtNode[n_nodes + 1]   one per object, depth-first pre-order (= the reference's visiting order,
+//                         rendering/world.rs:29-32,66-68), plus one inert trailing record so that the traversal may
+//                         always prefetch record i+1.  A group's subtree is nodes (i, skip); its children are at
 //                         nesting depth + 1.  Every node carries rows 0..2 of the inverse of its LOCAL
 //                         transformation: rays are taken down the hierarchy one local inverse at a time, as
 //                         World::collect_intersections / Object::intersect do (world.rs:53-58, objects.rs:121-126).
-//                         The node index is wave-uniform during traversal, so these are scalar loads.
+//                         The node index is wave-uniform during traversal, so these are scalar loads; the fields the
+//                         traversal needs for every node (matrix + the four words after it) are contiguous.
 //   RtSurface[n_leaves]   one per leaf: rows 0..2 of the inverse of the cached WORLD transformation (normals and
 //                         patterns use that one, objects.rs:87-105) plus material and pattern.  Read per lane, only
 //                         for the object a ray actually hit.
@@ -14,15 +16,20 @@
 
 #include <stdint.h>
 
+// RtNode.xform: structure of `inv`, found on the host by exact comparison.  The traversal skips the products with
+// exact zeros (and with exact ones for the identity); that changes no value, only possibly the sign of a zero.
+enum { RT_XFORM_GENERAL = 0, RT_XFORM_DIAGONAL = 1 /* scale + translation */, RT_XFORM_IDENTITY = 2 };
+
 struct RtNode {
     double inv[12];   // rows 0..2 of inverse(transformation), row-major 3x4
-    double a[6];      // group: bounds min.xyz, max.xyz (in the group's own space); leaf: a[0]=minimum, a[1]=maximum
     int32_t kind;     // RT_SPHERE .. RT_GROUP
+    int32_t xform;    // RT_XFORM_*
+    int32_t leaf;     // index into RtSurface[], -1 for groups
     int32_t skip;     // index of the first node after this node's subtree
     int32_t closed;   // cylinder / cone caps
-    int32_t leaf;     // index into RtSurface[], -1 for groups
     int32_t object;   // index into rt_world_desc.objects
-    int32_t _pad[3];
+    int32_t _pad[2];
+    double a[6];      // group: bounds min.xyz, max.xyz (in the group's own space); leaf: a[0]=minimum, a[1]=maximum
 };
 
 struct RtSurface {

@@ -23,6 +23,15 @@ void rows3(const Matrix4 &m, double out[12]) {
         for (int c = 0; c < 4; ++c) out[r * 4 + c] = m.d[r][c];
 }
 
+// Structure of a 3x4 affine matrix by EXACT comparison (-0.0 == 0.0): which products the device may skip.
+int32_t classify(const double m[12]) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            if (r != c && m[r * 4 + c] != 0.0) return RT_XFORM_GENERAL;
+    if (m[0] == 1.0 && m[5] == 1.0 && m[10] == 1.0 && m[3] == 0.0 && m[7] == 0.0 && m[11] == 0.0) return RT_XFORM_IDENTITY;
+    return RT_XFORM_DIAGONAL;
+}
+
 // Shape::bounds of the leaf kinds
 Bounds leaf_bounds(const rt_object_desc &o) {
     switch (o.kind) {
@@ -74,6 +83,7 @@ struct Builder {
             RtNode &n = out.nodes[ni];
             std::memset(&n, 0, sizeof n);
             rows3(*Tinv, n.inv);
+            n.xform = classify(n.inv);
             n.kind = o.kind;
             n.closed = o.closed ? 1 : 0;
             n.leaf = -1;
