@@ -714,7 +714,7 @@ __device__ __forceinline__ SceneK scene_k(const DeviceScene &d, int max_depth) {
 
 // Camera::render (rendering/camera.rs:56-67) for the rows of `rows`.  Workgroup = 16x16 pixels, wave = 8x8.
 template <bool STATS, int NEST>
-__global__ __launch_bounds__(256) void render_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth,
+__global__ __launch_bounds__(256, 4) void render_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth,
                                                      double *__restrict__ rgb, unsigned long long *counters) {
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main() -> None:
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    needle = sys.argv[2] if len(sys.argv) > 2 else "render_kernel<false>"
+    needle = sys.argv[2] if len(sys.argv) > 2 else "render_kernel<false"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -31,7 +31,7 @@ def main() -> None:
     with open(stats) as f:
         for row in csv.DictReader(f):
             name = row["Name"]
-            short = name.split("(")[0].replace("void rt::(anonymous namespace)::", "")
+            short = name.replace("void rt::(anonymous namespace)::", "").split("(")[0]
             lines.append(f"| `{short}` | {row['Calls']} | {float(row['AverageNs']) / 1e6:.4f} | {float(row['MinNs']) / 1e6:.4f} | "
                          f"{float(row['MaxNs']) / 1e6:.4f} | {float(row['Percentage']):.2f} |")
             if needle in name:
