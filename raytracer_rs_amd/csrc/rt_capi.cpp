@@ -161,8 +161,8 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     int rc = rt::flatten_world(*world, sc->flat, err);
     if (rc != RT_OK) return set_error(rc, err);
     sc->object_to_leaf.assign(world->n_objects, -1);
-    for (const RtNode &n : sc->flat.nodes)
-        if (n.leaf >= 0) sc->object_to_leaf[(size_t)n.object] = n.leaf;
+    for (size_t leaf = 0; leaf < sc->flat.surfaces.size(); ++leaf)
+        sc->object_to_leaf[(size_t)sc->flat.surfaces[leaf].object] = (int32_t)leaf;
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -176,9 +176,9 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
 
     size_t nb = sc->flat.nodes.size() * sizeof(RtNode), sb = sc->flat.surfaces.size() * sizeof(RtSurface);
     // one inert record past the end: the traversal prefetches node i+1 while it works on node i
-    HIP_TRY(hipMalloc((void **)&sc->d_nodes, nb + sizeof(RtNode)));
-    HIP_TRY(hipMemset((char *)sc->d_nodes + nb, 0, sizeof(RtNode)));
-    e = hipMalloc((void **)&sc->d_surfaces, sb ? sb : sizeof(RtSurface));
+    e = hipMalloc((void **)&sc->d_nodes, nb + sizeof(RtNode));
+    if (e == hipSuccess) e = hipMemset((char *)sc->d_nodes + nb, 0, sizeof(RtNode));
+    if (e == hipSuccess) e = hipMalloc((void **)&sc->d_surfaces, sb ? sb : sizeof(RtSurface));
     if (e == hipSuccess) e = hipMalloc((void **)&sc->d_counters, RT_NUM_COUNTERS * sizeof(unsigned long long));
     if (e == hipSuccess && nb) e = hipMemcpy(sc->d_nodes, sc->flat.nodes.data(), nb, hipMemcpyHostToDevice);
     if (e == hipSuccess && sb) e = hipMemcpy(sc->d_surfaces, sc->flat.surfaces.data(), sb, hipMemcpyHostToDevice);

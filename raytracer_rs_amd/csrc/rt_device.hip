@@ -104,15 +104,23 @@ struct SceneK {
 
 // Closest hit so far: the smallest t >= 0, the earliest emitted winning ties -- the element
 // Intersection::hit (rendering/intersections.rs:37-39) finds first in the stably sorted list (world.rs:34).
+// `t` starts as NaN: `!(x >= NaN)` holds for every x, so the first non-negative candidate (even +infinity) is taken,
+// and from then on t is an ordinary number and `!(x >= t)` is `x < t`.  Candidates arrive in the reference's emission
+// order, so the strict comparison keeps the earliest of equal t's.  Written with selects: no branch per candidate.
 struct Best {
     double t;
     int leaf;
 };
-__device__ __forceinline__ void cand(double t, int leaf, Best &b) {
-    if (t >= 0.0 && (b.leaf < 0 || t < b.t)) {
-        b.t = t;
-        b.leaf = leaf;
-    }
+__device__ __forceinline__ void cand(bool ok, double t, int leaf, Best &b) {
+    const bool better = ok & (t >= 0.0) & !(t >= b.t);
+    b.t = better ? t : b.t;
+    b.leaf = better ? leaf : b.leaf;
+}
+// Two candidates of ONE object with ta <= tb (or a NaN among them), emitted ta first: the later one can only win
+// when the earlier one is not eligible, so one update does for both.
+__device__ __forceinline__ void cand_ordered(bool oka, double ta, bool okb, double tb, int leaf, Best &b) {
+    const bool first = oka & (ta >= 0.0);
+    cand(first | okb, first ? ta : tb, leaf, b);
 }
 
 // geometry/cubes.rs:41-59 (threshold EPSILON, extents -1..1) and geometry/bounds.rs:110-128 (threshold 1e-10)
@@ -128,17 +136,13 @@ __device__ __forceinline__ void check_axis(double origin, double direction, doub
         a = n0 * INFINITY;
         b = n1 * INFINITY;
     }
-    if (a > b) {
-        tmin = b;
-        tmax = a;
-    } else {
-        tmin = a;
-        tmax = b;
-    }
+    const bool swap = a > b;
+    tmin = swap ? b : a;
+    tmax = swap ? a : b;
 }
 
 // geometry/bounds.rs:94-106; v_max_f64 / v_min_f64 return the non-NaN operand like f64::max / f64::min
-__device__ __forceinline__ bool aabb_hit(cdp bb, V3 o, V3 d) {
+__device__ __forceinline__ bool aabb_hit(const double (&bb)[6], V3 o, V3 d) {
     double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
     check_axis(o.x, d.x, bb[0], bb[3], AABB_EPS, xtmin, xtmax);
     check_axis(o.y, d.y, bb[1], bb[4], AABB_EPS, ytmin, ytmax);
@@ -148,8 +152,8 @@ __device__ __forceinline__ bool aabb_hit(cdp bb, V3 o, V3 d) {
     return tmin <= tmax;
 }
 
-// geometry/sphere.rs:51-74
-__device__ __forceinline__ bool hit_sphere(V3 o, V3 d, int leaf, Best &best) {
+// geometry/sphere.rs:51-74.  a = d.d >= 0, so (-b - sq)/(2a) <= (-b + sq)/(2a) unless one is NaN.
+__device__ __forceinline__ bool hit_sphere(V3 o, V3 d, bool on, int leaf, Best &best) {
     double a = dot(d, d);
     double b = 2.0 * dot(d, o);
     double c = dot(o, o) - 1.0;
@@ -157,20 +161,19 @@ __device__ __forceinline__ bool hit_sphere(V3 o, V3 d, int leaf, Best &best) {
     if (disc < 0.0) return false;
     double sq = sqrt(disc);
     double den = 2.0 * a;
-    cand((-b - sq) / den, leaf, best);
-    cand((-b + sq) / den, leaf, best);
+    cand_ordered(on, (-b - sq) / den, on, (-b + sq) / den, leaf, best);
     return true;
 }
 
 // geometry/planes.rs:46-56
-__device__ __forceinline__ bool hit_plane(V3 o, V3 d, int leaf, Best &best) {
+__device__ __forceinline__ bool hit_plane(V3 o, V3 d, bool on, int leaf, Best &best) {
     if (fabs(d.y) < EPS) return false;
-    cand(-o.y / d.y, leaf, best);
+    cand(on, -o.y / d.y, leaf, best);
     return true;
 }
 
-// geometry/cubes.rs:63-86
-__device__ __forceinline__ bool hit_cube(V3 o, V3 d, int leaf, Best &best) {
+// geometry/cubes.rs:63-86.  Both roots are emitted only when !(tmin > tmax).
+__device__ __forceinline__ bool hit_cube(V3 o, V3 d, bool on, int leaf, Best &best) {
     double tmin, tmax, ytmin, ytmax, ztmin, ztmax;
     check_axis(o.x, d.x, -1.0, 1.0, EPS, tmin, tmax);
     check_axis(o.y, d.y, -1.0, 1.0, EPS, ytmin, ytmax);
@@ -181,77 +184,65 @@ __device__ __forceinline__ bool hit_cube(V3 o, V3 d, int leaf, Best &best) {
     tmin = fmax(tmin, ztmin);
     tmax = fmin(tmax, ztmax);
     if (tmin > tmax) return false;
-    cand(tmin, leaf, best);
-    cand(tmax, leaf, best);
+    cand_ordered(on, tmin, on, tmax, leaf, best);
     return true;
 }
 
 // geometry/cylinders.rs:124-144 (radius 1) and geometry/cones.rs:140-161 (radius |y|)
 template <bool CONE>
-__device__ __forceinline__ bool hit_caps(V3 o, V3 d, double minimum, double maximum, int closed, int leaf,
+__device__ __forceinline__ bool hit_caps(V3 o, V3 d, double minimum, double maximum, bool closed, bool on, int leaf,
                                          Best &best) {
     if (!closed || fabs(d.y - 0.0) < EPS) return false;
-    bool any = false;
-    {
-        double t = (minimum - o.y) / d.y;
-        double x = o.x + t * d.x;
-        double z = o.z + t * d.z;
-        double r = CONE ? fabs(minimum) : 1.0;
-        double r2 = CONE ? r * r : 1.0;
-        if ((x * x + z * z) <= r2) {
-            cand(t, leaf, best);
-            any = true;
-        }
-    }
-    {
-        double t = (maximum - o.y) / d.y;
-        double x = o.x + t * d.x;
-        double z = o.z + t * d.z;
-        double r = CONE ? fabs(maximum) : 1.0;
-        double r2 = CONE ? r * r : 1.0;
-        if ((x * x + z * z) <= r2) {
-            cand(t, leaf, best);
-            any = true;
-        }
-    }
-    return any;
+    double t0 = (minimum - o.y) / d.y;
+    double x0 = o.x + t0 * d.x;
+    double z0 = o.z + t0 * d.z;
+    double r0 = CONE ? fabs(minimum) : 1.0;
+    const bool in0 = (x0 * x0 + z0 * z0) <= (CONE ? r0 * r0 : 1.0);
+    cand(in0 & on, t0, leaf, best);
+    double t1 = (maximum - o.y) / d.y;
+    double x1 = o.x + t1 * d.x;
+    double z1 = o.z + t1 * d.z;
+    double r1 = CONE ? fabs(maximum) : 1.0;
+    const bool in1 = (x1 * x1 + z1 * z1) <= (CONE ? r1 * r1 : 1.0);
+    cand(in1 & on, t1, leaf, best);
+    return in0 | in1;
+}
+
+// The two wall roots of a cylinder or cone, each kept when its y lies strictly between the limits
+// (cylinders.rs:78-96, cones.rs:85-103)
+__device__ __forceinline__ bool wall_roots(V3 o, V3 d, double b, double sq, double den, double minimum, double maximum,
+                                           bool on, int leaf, Best &best) {
+    double t0 = (-b - sq) / den;
+    double t1 = (-b + sq) / den;
+    const bool swap = t0 > t1;
+    double ta = swap ? t1 : t0;
+    double tb = swap ? t0 : t1;
+    double y0 = o.y + ta * d.y;
+    double y1 = o.y + tb * d.y;
+    const bool in0 = minimum < y0 && y0 < maximum;
+    const bool in1 = minimum < y1 && y1 < maximum;
+    cand_ordered(in0 & on, ta, in1 & on, tb, leaf, best);
+    return in0 | in1;
 }
 
 // geometry/cylinders.rs:57-99
-__device__ __forceinline__ bool hit_cylinder(V3 o, V3 d, double minimum, double maximum, int closed, int leaf,
-                                             Best &best) {
+__device__ __forceinline__ bool hit_cylinder(V3 o, V3 d, double minimum, double maximum, bool closed, bool on,
+                                             int leaf, Best &best) {
     double a = d.x * d.x + d.z * d.z;
-    if (fabs(a - 0.0) < EPS) return hit_caps<false>(o, d, minimum, maximum, closed, leaf, best);
-    double b = 2.0 * o.x * d.x + 2.0 * o.z * d.z;
-    double c = o.x * o.x + o.z * o.z - 1.0;
-    double disc = b * b - 4.0 * a * c;
-    if (disc < 0.0) return false;  // no cap test on this branch (cylinders.rs:73-75)
-    double sq = sqrt(disc);
-    double den = 2.0 * a;
-    double t0 = (-b - sq) / den;
-    double t1 = (-b + sq) / den;
-    if (t0 > t1) {
-        double tmp = t0;
-        t0 = t1;
-        t1 = tmp;
-    }
     bool any = false;
-    double y0 = o.y + t0 * d.y;
-    double y1 = o.y + t1 * d.y;
-    if (minimum < y0 && y0 < maximum) {
-        cand(t0, leaf, best);
-        any = true;
+    if (!(fabs(a - 0.0) < EPS)) {
+        double b = 2.0 * o.x * d.x + 2.0 * o.z * d.z;
+        double c = o.x * o.x + o.z * o.z - 1.0;
+        double disc = b * b - 4.0 * a * c;
+        if (disc < 0.0) return false;  // no cap test on this branch (cylinders.rs:73-75)
+        any = wall_roots(o, d, b, sqrt(disc), 2.0 * a, minimum, maximum, on, leaf, best);
     }
-    if (minimum < y1 && y1 < maximum) {
-        cand(t1, leaf, best);
-        any = true;
-    }
-    bool caps = hit_caps<false>(o, d, minimum, maximum, closed, leaf, best);
-    return any || caps;
+    const bool caps = hit_caps<false>(o, d, minimum, maximum, closed, on, leaf, best);
+    return any | caps;
 }
 
 // geometry/cones.rs:57-107
-__device__ __forceinline__ bool hit_cone(V3 o, V3 d, double minimum, double maximum, int closed, int leaf,
+__device__ __forceinline__ bool hit_cone(V3 o, V3 d, double minimum, double maximum, bool closed, bool on, int leaf,
                                          Best &best) {
     double a = d.x * d.x - d.y * d.y + d.z * d.z;
     double b = 2.0 * o.x * d.x - 2.0 * o.y * d.y + 2.0 * o.z * d.z;
@@ -261,167 +252,144 @@ __device__ __forceinline__ bool hit_cone(V3 o, V3 d, double minimum, double maxi
         if (!(fabs(b - 0.0) < EPS)) {
             double t = -c / (2.0 * b);
             double y = o.y + t * d.y;
-            if (minimum < y && y < maximum) {
-                cand(t, leaf, best);
-                any = true;
-            }
+            any = minimum < y && y < maximum;
+            cand(any & on, t, leaf, best);
         }
     } else {
         double disc = b * b - 4.0 * a * c;
-        if (!(disc < 0.0)) {  // a negative discriminant still falls through to the caps (cones.rs:80-83)
-            double sq = sqrt(disc);
-            double den = 2.0 * a;
-            double t0 = (-b - sq) / den;
-            double t1 = (-b + sq) / den;
-            if (t0 > t1) {
-                double tmp = t0;
-                t0 = t1;
-                t1 = tmp;
-            }
-            double y0 = o.y + t0 * d.y;
-            if (minimum < y0 && y0 < maximum) {
-                cand(t0, leaf, best);
-                any = true;
-            }
-            double y1 = o.y + t1 * d.y;
-            if (minimum < y1 && y1 < maximum) {
-                cand(t1, leaf, best);
-                any = true;
-            }
-        }
+        // a negative discriminant still falls through to the caps (cones.rs:80-83)
+        if (!(disc < 0.0)) any = wall_roots(o, d, b, sqrt(disc), 2.0 * a, minimum, maximum, on, leaf, best);
     }
-    bool caps = hit_caps<true>(o, d, minimum, maximum, closed, leaf, best);
-    return any || caps;
+    const bool caps = hit_caps<true>(o, d, minimum, maximum, closed, on, leaf, best);
+    return any | caps;
 }
 
-// The per-node fields every traversal step needs, held in SGPRs (the node index is wave-uniform): the 3x4 inverse
-// matrix (24 dwords) and the four words after it (kind, xform, leaf, skip) -- the first 112 bytes of an RtNode,
-// fetched as three wide scalar loads.
+// A node record as it arrives in SGPRs (the node index is wave-uniform): two or three wide scalar loads.
+//   a[0..15]  inv[0..7]
+//   b[0..7]   inv[8..11];  b[8..11] tag, xform, leaf, skip;  b[12..15] a[0], a[1] (cylinder / cone limits)
+//   c[0..7]   a[2..5] -- with b[12..15] a group's bounds; fetched only by kernels built for scenes with groups
 //
-// The loads are `volatile`: that pins them where they are written.  The traversal asks for node i+1 at the top of
-// the iteration that works on node i, and without the qualifier the optimiser sinks that request down to its first
-// use (the next iteration), which exposes the full scalar-cache latency once per node.  The compiler still tracks
-// the outstanding loads itself and places the s_waitcnt before the first use.
+// The loads are `volatile`: that pins them where they are written.  The traversal asks for the following record as
+// soon as the matrix of the current one has been used, and without the qualifier the optimiser sinks that request
+// down to its first use (the next iteration), which exposes the full scalar-cache latency once per node.  The
+// compiler still tracks the outstanding loads itself and places the s_waitcnt before the first use.
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 struct NodeRaw {
-    i32x16 a;  // inv[0..7]
-    i32x8 b;   // inv[8..11]
-    i32x4 c;   // kind, xform, leaf, skip
+    i32x16 a;
+    i32x16 b;
+    i32x8 c;
 };
-static_assert(offsetof(RtNode, kind) == 96 && offsetof(RtNode, skip) == 108, "RtNode hot fields moved");
+static_assert(sizeof(RtNode) == 160 && offsetof(RtNode, tag) == 96 && offsetof(RtNode, a) == 112, "RtNode layout moved");
 
+template <bool WIDE>
 __device__ __forceinline__ NodeRaw node_fetch(NodeP n) {
     const char RT_CONSTANT_AS *p = (const char RT_CONSTANT_AS *)n;
     NodeRaw r;
     r.a = *(const volatile i32x16 RT_CONSTANT_AS *)(p);
-    r.b = *(const volatile i32x8 RT_CONSTANT_AS *)(p + 64);
-    r.c = *(const volatile i32x4 RT_CONSTANT_AS *)(p + 96);
+    r.b = *(const volatile i32x16 RT_CONSTANT_AS *)(p + 64);
+    if (WIDE) r.c = *(const volatile i32x8 RT_CONSTANT_AS *)(p + 128);
     return r;
 }
 
-struct NodeRegs {
-    double m[12];
-    int kind, xform, leaf, skip;
-};
-__device__ __forceinline__ double dwords_to_double(int lo, int hi) {
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ NodeRegs node_regs(const NodeRaw &r) {
-    NodeRegs n;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) n.m[k] = dwords_to_double(r.a[2 * k], r.a[2 * k + 1]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) n.m[8 + k] = dwords_to_double(r.b[2 * k], r.b[2 * k + 1]);
-    // The loads are scalar (uniform address), but the optimiser treats the result of a volatile load as possibly
-    // divergent; say explicitly that the words steering the traversal are wave-uniform.
-    n.kind = __builtin_amdgcn_readfirstlane(r.c[0]);
-    n.xform = __builtin_amdgcn_readfirstlane(r.c[1]);
-    n.leaf = __builtin_amdgcn_readfirstlane(r.c[2]);
-    n.skip = __builtin_amdgcn_readfirstlane(r.c[3]);
-    return n;
-}
+__device__ __forceinline__ double dwords_to_double(int lo, int hi) { return __hiloint2double(hi, lo); }
+// The loads are scalar (uniform address), but the optimiser treats the result of a volatile load as possibly
+// divergent; the words that steer the traversal are marked wave-uniform explicitly.
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Ray::transform (rendering/rays.rs:22-24) by a node's inverse.  xform is wave-uniform, so this is a scalar branch:
 // a scale-and-translate inverse (every sphere of a typical scene) needs 9 operations instead of 33, an identity none.
-__device__ __forceinline__ void to_local(const NodeRegs &n, V3 o, V3 d, V3 &lo, V3 &ld) {
-    if (n.xform == RT_XFORM_IDENTITY) {
+__device__ __forceinline__ void to_local(const NodeRaw &r, int xform, V3 o, V3 d, V3 &lo, V3 &ld) {
+    double m[12];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = dwords_to_double(r.a[2 * k], r.a[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[8 + k] = dwords_to_double(r.b[2 * k], r.b[2 * k + 1]);
+    if (xform == RT_XFORM_IDENTITY) {
         lo = o;
         ld = d;
-    } else if (n.xform == RT_XFORM_DIAGONAL) {
-        lo = mk(n.m[0] * o.x + n.m[3], n.m[5] * o.y + n.m[7], n.m[10] * o.z + n.m[11]);
-        ld = mk(n.m[0] * d.x, n.m[5] * d.y, n.m[10] * d.z);
+    } else if (xform == RT_XFORM_DIAGONAL) {
+        lo = mk(m[0] * o.x + m[3], m[5] * o.y + m[7], m[10] * o.z + m[11]);
+        ld = mk(m[0] * d.x, m[5] * d.y, m[10] * d.z);
     } else {
-        lo = mul_point(n.m, o);
-        ld = mul_vector(n.m, d);
+        lo = mul_point(m, o);
+        ld = mul_vector(m, d);
     }
 }
 
 // World::intersect / collect_intersections (rendering/world.rs:27-78) over the node range [begin,end) at nesting
 // level D of a scene whose deepest level is NEST, for the lanes with `active` set.  begin, end and the running index
-// are wave-uniform.  The record of node i+1 is requested while node i is being worked on, so the scalar-cache
-// latency of one node hides behind the arithmetic of the previous one.
+// are wave-uniform.  Per node: take the ray into the node's space (this uses up the matrix), request the following
+// record into the registers the matrix occupied, then run the shape or bounds test while that request is in flight.
 template <int D, int NEST, bool STATS>
 __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end, V3 o, V3 d, bool active, Best &best,
                                             Ctr<STATS> &ctr) {
+    constexpr bool WIDE = NEST > 0;
     if (begin >= end) return;
-    NodeRaw raw = node_fetch(S.nodes + begin);
+    NodeRaw raw = node_fetch<WIDE>(S.nodes + begin);
     // Consume one word of the first record here, so that its arrival is awaited before the loop and not at the top
     // of every iteration (where the wait would also cover the request for the following record).
-    asm volatile("" ::"s"(raw.c[0]));
+    asm volatile("" ::"s"(raw.b[8]));
     int i = begin;
     while (i < end) {
-        NodeP np = S.nodes + i;
-        const NodeRegs cur = node_regs(raw);
-        NodeRaw nraw = node_fetch(np + 1);  // in flight while this node is worked on (the table has one spare record)
+        const int tag = uniform(raw.b[8]), xform = uniform(raw.b[9]), leaf = uniform(raw.b[10]), skip = uniform(raw.b[11]);
+        const int kind = tag & 0xff;
+        const double a0 = dwords_to_double(raw.b[12], raw.b[13]), a1 = dwords_to_double(raw.b[14], raw.b[15]);
+        V3 lo, ld;
+        to_local(raw, xform, o, d, lo, ld);
+        double bb[6];
+        if constexpr (D < NEST) {
+            bb[0] = a0;
+            bb[1] = a1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bb[2 + k] = dwords_to_double(raw.c[2 * k], raw.c[2 * k + 1]);
+        }
+        NodeRaw nraw = node_fetch<WIDE>(S.nodes + i + 1);  // the table has one spare record at its end
         int ni = i + 1;
-        if (D < NEST && cur.kind == RT_GROUP) {
+        if (D < NEST && kind == RT_GROUP) {
             if constexpr (D < NEST) {
                 bool inside = false;
-                V3 lo = mk(0.0, 0.0, 0.0), ld = mk(0.0, 0.0, 0.0);
                 if (active) {
-                    to_local(cur, o, d, lo, ld);
-                    inside = aabb_hit((cdp)np->a, lo, ld);
+                    inside = aabb_hit(bb, lo, ld);
                     ctr.add(C_XFORM);
                     ctr.add(C_AABB);
                 }
-                if (__ballot(inside) != 0ull) trace_range<D + 1, NEST, STATS>(S, i + 1, cur.skip, lo, ld, inside, best, ctr);
-                ni = cur.skip;
+                if (__ballot(inside) != 0ull) trace_range<D + 1, NEST, STATS>(S, i + 1, skip, lo, ld, inside, best, ctr);
+                ni = skip;
             }
-        } else if (cur.kind != RT_GROUP) {
-            if (active) {
-                V3 lo, ld;
-                to_local(cur, o, d, lo, ld);
-                bool any;
-                switch (cur.kind) {
-                    case RT_SPHERE: any = hit_sphere(lo, ld, cur.leaf, best); break;
-                    case RT_PLANE: any = hit_plane(lo, ld, cur.leaf, best); break;
-                    case RT_CUBE: any = hit_cube(lo, ld, cur.leaf, best); break;
-                    case RT_CYLINDER: any = hit_cylinder(lo, ld, np->a[0], np->a[1], np->closed, cur.leaf, best); break;
-                    default: any = hit_cone(lo, ld, np->a[0], np->a[1], np->closed, cur.leaf, best); break;
-                }
-                if (STATS) {
-                    ctr.add(C_XFORM);
-                    ctr.add(C_PRIM_TESTS + cur.kind);
-                    if (any) ctr.add(C_PRIM_HITS + cur.kind);
-                }
+        } else if (kind != RT_GROUP) {
+            // Lanes that are not `active` run the test too (there is no cheaper way to idle them) but cannot
+            // change their closest hit.
+            // At the top level the inactive lanes are the ones whose result nobody reads: no mask needed there.
+            const bool on = D == 0 ? true : active;
+            bool any;
+            switch (kind) {
+                case RT_SPHERE: any = hit_sphere(lo, ld, on, leaf, best); break;
+                case RT_PLANE: any = hit_plane(lo, ld, on, leaf, best); break;
+                case RT_CUBE: any = hit_cube(lo, ld, on, leaf, best); break;
+                case RT_CYLINDER: any = hit_cylinder(lo, ld, a0, a1, (tag & RT_NODE_CLOSED) != 0, on, leaf, best); break;
+                default: any = hit_cone(lo, ld, a0, a1, (tag & RT_NODE_CLOSED) != 0, on, leaf, best); break;
+            }
+            if (STATS && active) {
+                ctr.add(C_XFORM);
+                ctr.add(C_PRIM_TESTS + kind);
+                if (any) ctr.add(C_PRIM_HITS + kind);
             }
         } else {
-            ni = cur.skip;  // a group at the deepest level the scene declares: it has no children
+            ni = skip;  // a group at the deepest level the scene declares: it has no children
         }
         if constexpr (NEST > 0) {
-            if (ni != i + 1) nraw = node_fetch(S.nodes + ni);  // the subtree was stepped over: fetch the record wanted
+            if (ni != i + 1) nraw = node_fetch<WIDE>(S.nodes + ni);  // the subtree was stepped over: fetch the record wanted
         }
         raw = nraw;
-        i = __builtin_amdgcn_readfirstlane(ni);  // every operand above is wave-uniform; keep the index in an SGPR
+        i = uniform(ni);  // every operand above is wave-uniform; keep the index in an SGPR
     }
 }
 
 template <int NEST, bool STATS>
 __device__ __forceinline__ Best trace(const SceneK &S, V3 o, V3 d, bool active, Ctr<STATS> &ctr) {
     Best best;
-    best.t = 0.0;
+    best.t = __builtin_nan("");
     best.leaf = -1;
     if (STATS && active) ctr.add(C_RAYS);
     trace_range<0, NEST, STATS>(S, 0, S.n_nodes, o, d, active, best, ctr);

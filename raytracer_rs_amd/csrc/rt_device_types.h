@@ -7,8 +7,8 @@
 //                         nesting depth + 1.  Every node carries rows 0..2 of the inverse of its LOCAL
 //                         transformation: rays are taken down the hierarchy one local inverse at a time, as
 //                         World::collect_intersections / Object::intersect do (world.rs:53-58, objects.rs:121-126).
-//                         The node index is wave-uniform during traversal, so these are scalar loads; the fields the
-//                         traversal needs for every node (matrix + the four words after it) are contiguous.
+//                         The node index is wave-uniform during traversal, so a record is fetched with two or three
+//                         wide scalar loads (128 bytes for a leaf, all 160 when the scene has groups).
 //   RtSurface[n_leaves]   one per leaf: rows 0..2 of the inverse of the cached WORLD transformation (normals and
 //                         patterns use that one, objects.rs:87-105) plus material and pattern.  Read per lane, only
 //                         for the object a ray actually hit.
@@ -22,15 +22,13 @@ enum { RT_XFORM_GENERAL = 0, RT_XFORM_DIAGONAL = 1 /* scale + translation */, RT
 
 struct RtNode {
     double inv[12];   // rows 0..2 of inverse(transformation), row-major 3x4
-    int32_t kind;     // RT_SPHERE .. RT_GROUP
+    int32_t tag;      // RT_SPHERE .. RT_GROUP in bits 0..7; bit 8: cylinder / cone is closed
     int32_t xform;    // RT_XFORM_*
     int32_t leaf;     // index into RtSurface[], -1 for groups
     int32_t skip;     // index of the first node after this node's subtree
-    int32_t closed;   // cylinder / cone caps
-    int32_t object;   // index into rt_world_desc.objects
-    int32_t _pad[2];
     double a[6];      // group: bounds min.xyz, max.xyz (in the group's own space); leaf: a[0]=minimum, a[1]=maximum
 };
+#define RT_NODE_CLOSED 0x100
 
 struct RtSurface {
     double inv_world[12];  // rows 0..2 of inverse(world_transformation)

@@ -84,10 +84,8 @@ struct Builder {
             std::memset(&n, 0, sizeof n);
             rows3(*Tinv, n.inv);
             n.xform = classify(n.inv);
-            n.kind = o.kind;
-            n.closed = o.closed ? 1 : 0;
+            n.tag = o.kind | (o.closed ? RT_NODE_CLOSED : 0);
             n.leaf = -1;
-            n.object = (int32_t)idx;
         }
 
         if (o.kind == RT_GROUP) {
