@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+# RT_AMD_LIB points a developer run at another build of the same library (A/B timing of kernel variants).
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")
 
 RT_OK = 0
 ERR_NAMES = {-1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NOT_INVERTIBLE", -3: "RT_ERR_MATERIAL", -4: "RT_ERR_HIP",

@@ -5,6 +5,7 @@
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -22,6 +23,8 @@ struct rt_scene {
     RtNode *d_nodes = nullptr;
     RtSurface *d_surfaces = nullptr;
     unsigned long long *d_counters = nullptr;
+    uint32_t *d_tiles = nullptr;  // tile-ordering scratch of launch_render, grown on demand
+    size_t tiles_cap = 0;         // in 32-bit words
     rt::DeviceScene dev;
     std::vector<int32_t> object_to_leaf;
     uint64_t device_bytes = 0;
@@ -205,6 +208,7 @@ void rt_scene_destroy(rt_scene *scene) {
         if (scene->d_nodes) (void)hipFree(scene->d_nodes);
         if (scene->d_surfaces) (void)hipFree(scene->d_surfaces);
         if (scene->d_counters) (void)hipFree(scene->d_counters);
+        if (scene->d_tiles) (void)hipFree(scene->d_tiles);
     }
     delete scene;
 }
@@ -219,6 +223,26 @@ int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out) {
     out->device_bytes = scene->device_bytes;
     out->device = scene->device;
     return RT_OK;
+}
+
+// Tile-ordering scratch of the handle, grown on demand (the handle is used by one render at a time).  RT_TILE_ORDER=0
+// in the environment turns the ordering off (developer A/B switch).
+static hipError_t tile_scratch(const rt_scene *scene_c, const rt_camera_desc *camera, const rt::RowMap &rows, uint32_t **out) {
+    static const bool enabled = [] { const char *e = getenv("RT_TILE_ORDER"); return !(e && e[0] == '0'); }();
+    *out = nullptr;
+    if (!enabled || rows.n_rows == 0) return hipSuccess;
+    rt_scene *scene = const_cast<rt_scene *>(scene_c);
+    const size_t need = rt::render_scratch_words(camera->hsize, rows.n_rows);
+    if (need > scene->tiles_cap) {
+        if (scene->d_tiles) (void)hipFree(scene->d_tiles);
+        scene->d_tiles = nullptr;
+        scene->tiles_cap = 0;
+        hipError_t e = hipMalloc((void **)&scene->d_tiles, need * sizeof(uint32_t));
+        if (e != hipSuccess) return e;
+        scene->tiles_cap = need;
+    }
+    *out = scene->d_tiles;
+    return hipSuccess;
 }
 
 int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
@@ -236,7 +260,9 @@ int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const 
     if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (want_stats) HIP_TRY(hipMemsetAsync(scene->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), stream));
-    HIP_TRY(rt::launch_render(scene->dev, cam, rows, depth, rgb_device, want_stats ? scene->d_counters : nullptr, stream));
+    uint32_t *tiles = nullptr;
+    HIP_TRY(tile_scratch(scene, camera, rows, &tiles));
+    HIP_TRY(rt::launch_render(scene->dev, cam, rows, depth, rgb_device, want_stats ? scene->d_counters : nullptr, tiles, stream));
     if (want_stats) {
         unsigned long long c[RT_NUM_COUNTERS];
         HIP_TRY(hipMemcpyAsync(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
@@ -264,12 +290,14 @@ int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_rend
     const size_t count = (size_t)rows.n_rows * row_vals;
     DeviceBuffer<double> buf;
     HIP_TRY(buf.alloc(count));
+    uint32_t *tiles = nullptr;
+    HIP_TRY(tile_scratch(scene, camera, rows, &tiles));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     HIP_TRY(hipEventCreate(&ev0));
     hipError_t e = hipEventCreate(&ev1);
     if (e == hipSuccess && want_stats) e = hipMemsetAsync(scene->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), nullptr);
     if (e == hipSuccess) e = hipEventRecord(ev0, nullptr);
-    if (e == hipSuccess) e = rt::launch_render(scene->dev, cam, rows, depth, buf.p, want_stats ? scene->d_counters : nullptr, nullptr);
+    if (e == hipSuccess) e = rt::launch_render(scene->dev, cam, rows, depth, buf.p, want_stats ? scene->d_counters : nullptr, tiles, nullptr);
     if (e == hipSuccess) e = hipEventRecord(ev1, nullptr);
     // packed rows -> their place in the caller's whole-frame buffer, one copy per band
     for (uint32_t r = 0; e == hipSuccess && r < rows.n_rows; r += rows.band_rows) {

@@ -21,9 +21,24 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <cstdlib>
 
 #include "../../include/raytracer_rs_amd.h"
 #include "rt_device.hpp"
+
+#ifdef RT_TIMING
+// Developer build: per-wave shader-clock totals of the phases of radiance() (tools/timing.py reads them).
+#define RT_TIMING_WAVES (1 << 20)
+__device__ unsigned long long g_rt_timing[RT_TIMING_WAVES][4];  // per wave: trace | shade<<32, real-time begin, iterations, lifetime | real-time lifetime<<40
+extern "C" int rt_debug_timing(unsigned long long *out, unsigned n_waves) {
+    if (n_waves > RT_TIMING_WAVES) n_waves = RT_TIMING_WAVES;
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rt_timing), (size_t)n_waves * 4 * sizeof(unsigned long long));
+    return e == hipSuccess ? 0 : -4;
+}
+#define RT_TIC(var) const long long var = clock64()
+#else
+#define RT_TIC(var)
+#endif
 
 namespace rt {
 namespace {
@@ -35,7 +50,7 @@ typedef const RtNode RT_CONSTANT_AS *NodeP;
 constexpr double EPS = 1e-5;          // core/floats.rs:2
 constexpr double AABB_EPS = 1e-10;    // geometry/bounds.rs:114
 constexpr double CHECKER_EPS = 1e-6;  // scene/patterns.rs:106
-constexpr int STACK_MAX = RT_MAX_DEPTH;
+constexpr int STACK_MAX = RT_MAX_DEPTH + 1;  // in memory: at most one parked ray per level, plus one while a hit pushes two
 
 enum {
     C_RAYS = 0, C_PRIMARY, C_SHADOW, C_REFLECT, C_REFRACT,
@@ -298,17 +313,16 @@ __device__ __forceinline__ double dwords_to_double(int lo, int hi) { return __hi
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Ray::transform (rendering/rays.rs:22-24) by a node's inverse.  xform is wave-uniform, so this is a scalar branch:
-// a scale-and-translate inverse (every sphere of a typical scene) needs 9 operations instead of 33, an identity none.
+// a scale-and-translate inverse (every sphere of a typical scene) needs 9 operations instead of 33.
 __device__ __forceinline__ void to_local(const NodeRaw &r, int xform, V3 o, V3 d, V3 &lo, V3 &ld) {
     double m[12];
 #pragma unroll
     for (int k = 0; k < 8; ++k) m[k] = dwords_to_double(r.a[2 * k], r.a[2 * k + 1]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) m[8 + k] = dwords_to_double(r.b[2 * k], r.b[2 * k + 1]);
-    if (xform == RT_XFORM_IDENTITY) {
-        lo = o;
-        ld = d;
-    } else if (xform == RT_XFORM_DIAGONAL) {
+    if (xform != RT_XFORM_GENERAL) {
+        // scale and translation only (the identity included: multiplying by its exact ones and adding its exact
+        // zeros costs the same as copying the ray and needs no third code path)
         lo = mk(m[0] * o.x + m[3], m[5] * o.y + m[7], m[10] * o.z + m[11]);
         ld = mk(m[0] * d.x, m[5] * d.y, m[10] * d.z);
     } else {
@@ -458,10 +472,26 @@ __device__ __forceinline__ V3 pattern_color(const RtSurface *s, V3 p) {
     }
 }
 
-// Material::lighting (scene/materials.rs:122-172) with Pattern::color_at_object (scene/patterns.rs:137-146)
+// x^n for a small non-negative integer n by binary powering: at most 2*12 multiplications, relative error below
+// n * 2^-53.  Phong exponents are such integers in every scene file; the general pow is kept for the rest.
+__device__ __forceinline__ double powi_small(double x, unsigned n) {
+    double r = 1.0;
+    while (n != 0u) {
+        if (n & 1u) r = r * x;
+        x = x * x;
+        n >>= 1;
+    }
+    return r;
+}
+constexpr double POWI_MAX = 4096.0;
+
+// Material::lighting (scene/materials.rs:122-172) with Pattern::color_at_object (scene/patterns.rs:137-146), evaluated
+// BEFORE the shadow ray is traced: returns the result for in_shadow = true in `shadowed` (ambient only: the reference
+// adds black diffuse and specular terms, which changes nothing) and the result for in_shadow = false in `lit`.
+// `flags` bit 0: the diffuse branch is taken when not in shadow; bit 1: powf is evaluated then.
 template <bool STATS>
-__device__ __forceinline__ V3 lighting(const RtSurface *s, const RtLight &light, V3 point, V3 eye, V3 normal,
-                                       bool in_shadow, Ctr<STATS> &ctr) {
+__device__ __forceinline__ void lighting(const RtSurface *s, const RtLight &light, V3 point, V3 eye, V3 normal,
+                                         V3 &shadowed, V3 &lit, int &flags, Ctr<STATS> &ctr) {
     V3 color;
     if (s->pattern_kind != RT_PATTERN_NONE) {
         V3 object_point = mul_point(s->inv_world, point);
@@ -478,19 +508,26 @@ __device__ __forceinline__ V3 lighting(const RtSurface *s, const RtLight &light,
     lv = lv / magnitude(lv);
     V3 ambient = effective * s->ambient;
     double ldn = dot(lv, normal);
-    V3 diffuse = mk(0.0, 0.0, 0.0), specular = mk(0.0, 0.0, 0.0);
-    if (ldn >= 0.0 && !in_shadow) {
-        ctr.add(C_LIT);
-        diffuse = (effective * s->diffuse) * ldn;
+    shadowed = ambient;
+    lit = ambient;
+    flags = 0;
+    if (ldn >= 0.0) {
+        flags = 1;
+        V3 diffuse = (effective * s->diffuse) * ldn;
+        V3 specular = mk(0.0, 0.0, 0.0);
         V3 rv = reflect(-lv, normal);
         double rde = dot(rv, eye);
         if (rde > 0.0) {
-            ctr.add(C_SPECULAR);
-            double factor = pow(rde, s->shininess);
+            flags = 3;
+            const double shininess = s->shininess;
+            double factor;
+            const bool small_int = shininess >= 0.0 && shininess <= POWI_MAX && floor(shininess) == shininess;
+            if (small_int) factor = powi_small(rde, (unsigned)shininess);
+            else factor = pow(rde, shininess);
             specular = (li * s->specular) * factor;
         }
+        lit = (ambient + diffuse) + specular;
     }
-    return (ambient + diffuse) + specular;
 }
 
 // Camera::ray_for_pixel (rendering/camera.rs:39-54) with the inverse of the view transform precomputed
@@ -513,30 +550,69 @@ enum { MODE_IDLE = 0, MODE_RADIANCE = 1, MODE_SHADOW = 2 };
 // reflected = child*reflectivity, world.rs:167, and the Schlick factors when both are positive) is evaluated as a
 // sum over the nodes of the ray tree of  weight(node) * surface(node), weight being the product of the factors on
 // the path from the root.  That differs from the nested form only by floating-point reassociation (a few ulp).
+//
+// Per hit, everything is computed at once -- the surface colour for both outcomes of the shadow test, and the
+// reflection and refraction rays, which go onto a per-lane stack (refraction first, so the reflection subtree is
+// walked first) -- and then the shadow ray is traced.  While it is in flight a lane keeps only the two candidate
+// sums and the distance to the light; when it returns the lane picks one and pops its next ray.
 template <int NEST, bool STATS>
 __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 rd, int remaining0, V3 &acc,
                                          Ctr<STATS> &ctr) {
     int mode = valid ? MODE_RADIANCE : MODE_IDLE;
     double w = 1.0;
     int remaining = remaining0;
-    acc = mk(0.0, 0.0, 0.0);
+    acc = mk(0.0, 0.0, 0.0);   // while a shadow ray is in flight: the sum if the hit is in shadow
+    V3 acc_lit = acc;          // ... and the sum if it is not
+    double h_dist = 0.0;
+    int h_flags = 0;
 
-    // the hit being shaded while its shadow ray is in flight
-    V3 h_point = mk(0, 0, 0), h_normal = mk(0, 0, 0), h_dir = mk(0, 0, 0);
-    double h_dist = 0.0, h_t = 0.0;
-    int h_leaf = -1;
-
-    // parked refraction rays: origin, direction, weight; remaining budget
+    // Pending rays (origin, direction, weight, remaining budget), last in first out.  The newest one lives in
+    // registers (nx_*, valid while nx_rem >= 0), older ones in a per-lane array in scratch memory.  A pop hands out
+    // the register copy and at once asks memory for the entry below it, so that load completes during the next
+    // traversal instead of being waited for.
+    V3 nx_o = mk(0, 0, 0), nx_d = mk(0, 0, 0);
+    double nx_w = 0.0;
+    int nx_rem = -1;
     double stk[STACK_MAX][7];
     int stk_rem[STACK_MAX];
     int sp = 0;
+    auto push = [&](V3 po, V3 pd, double pw, int prem) {
+        if (nx_rem >= 0) {
+            stk[sp][0] = nx_o.x; stk[sp][1] = nx_o.y; stk[sp][2] = nx_o.z;
+            stk[sp][3] = nx_d.x; stk[sp][4] = nx_d.y; stk[sp][5] = nx_d.z;
+            stk[sp][6] = nx_w;
+            stk_rem[sp] = nx_rem;
+            sp++;
+        }
+        nx_o = po;
+        nx_d = pd;
+        nx_w = pw;
+        nx_rem = prem;
+    };
 
     const V3 light_pos = mk(S.light.position[0], S.light.position[1], S.light.position[2]);
 
+#ifdef RT_TIMING
+    long long tm_trace = 0, tm_shade = 0, tm_iters = 0, tm_lanes = 0;
+    const long long tm_begin = clock64();
+    const long long tm_rbegin = wall_clock64();
+#endif
     while (__ballot(mode != MODE_IDLE) != 0ull) {
+        RT_TIC(tm0);
         Best best = trace<NEST, STATS>(S, ro, rd, mode != MODE_IDLE, ctr);
+        RT_TIC(tm1);
         bool need_next = false;
-        if (mode == MODE_RADIANCE) {
+        if (mode == MODE_SHADOW) {
+            const bool in_shadow = best.leaf >= 0 && best.t < h_dist;  // world.rs:145-148
+            if (!in_shadow) {
+                acc = acc_lit;
+                if (STATS) {
+                    if (h_flags & 1) ctr.add(C_LIT);
+                    if (h_flags & 2) ctr.add(C_SPECULAR);
+                }
+            }
+            need_next = true;
+        } else if (mode == MODE_RADIANCE) {
             if (best.leaf >= 0 && S.light.has_light) {
                 // Intersection::prepare_computations (rendering/intersections.rs:45-63)
                 const RtSurface *s = S.surfaces + best.leaf;
@@ -545,118 +621,123 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
                 V3 eye = -rd;
                 if (dot(normal, eye) < 0.0) normal = -normal;
                 V3 over = point + normal * EPS;
+                ctr.add(C_SHADES);
+
+                V3 shadowed, lit;
+                lighting<STATS>(s, S.light, point, eye, normal, shadowed, lit, h_flags, ctr);
+                acc_lit = acc + lit * w;
+                acc = acc + shadowed * w;
+
+                const double reflectivity = s->reflectivity;
+                const double transparency = s->transparency;
+                bool do_reflect = remaining != 0 && reflectivity != 0.0;   // world.rs:156-162
+                bool do_refract = remaining != 0 && transparency != 0.0;   // world.rs:175-181
+                double cos_i = dot(eye, normal);
+                // n1/n2 as Intersection::prepare_computations leaves them when handed the one-element list [self]
+                // (intersections.rs:41-43,66-103): n1 = 1.0, n2 = the hit object's refractive index; a non-finite t
+                // fails float_equal(t, t) and leaves both at 1.0.
+                const double n1 = 1.0;
+                const double n2 = (fabs(best.t - best.t) < EPS) ? s->refractive_index : 1.0;
+                V3 refr_dir = mk(0.0, 0.0, 0.0);
+                if (do_refract) {  // world.rs:183-194
+                    ctr.add(C_REFRACT_SETUPS);
+                    double n_ratio = n1 / n2;
+                    double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+                    if (sin2_t > 1.0) {
+                        do_refract = false;
+                    } else {
+                        double cos_t = sqrt(1.0 - sin2_t);
+                        refr_dir = normal * (n_ratio * cos_i - cos_t) - eye * n_ratio;
+                    }
+                }
+                double w_reflect = w * reflectivity;
+                double w_refract = w * transparency;
+                if (reflectivity > 0.0 && transparency > 0.0) {  // world.rs:105-108, intersections.rs:123-136
+                    ctr.add(C_SCHLICK);
+                    double c = cos_i;
+                    double reflectance;
+                    bool total = false;
+                    if (n1 > n2) {
+                        double n = n1 / n2;
+                        double sin2_t = (n * n) * (1.0 - c * c);
+                        if (sin2_t > 1.0) total = true;
+                        c = sqrt(1.0 - sin2_t);
+                    }
+                    if (total) {
+                        reflectance = 1.0;
+                    } else {
+                        double q = (n1 - n2) / (n1 + n2);
+                        double r0 = q * q;
+                        double m = 1.0 - c;
+                        double m2 = m * m;
+                        double m5 = m * (m2 * m2);  // powi(5)
+                        reflectance = r0 + (1.0 - r0) * m5;
+                    }
+                    w_reflect = w_reflect * reflectance;
+                    w_refract = w_refract * (1.0 - reflectance);
+                }
+                const int child_remaining = remaining - 1;
+                if (do_refract) {  // under_point, direction (intersections.rs:63, world.rs:194)
+                    ctr.add(C_REFRACT);
+                    push(point - normal * EPS, refr_dir, w_refract, child_remaining);
+                }
+                if (do_reflect) {  // over_point, reflect_vector (intersections.rs:60-62)
+                    ctr.add(C_REFLECT);
+                    push(over, reflect(rd, normal), w_reflect, child_remaining);
+                }
+
                 // World::is_shadowed (rendering/world.rs:128-141)
                 V3 v = light_pos - over;
                 double distance = magnitude(v);
-                h_point = point;
-                h_normal = normal;
-                h_dir = rd;
                 h_dist = distance;
-                h_t = best.t;
-                h_leaf = best.leaf;
                 ro = over;
                 rd = v / distance;
                 mode = MODE_SHADOW;
-                ctr.add(C_SHADES);
                 ctr.add(C_SHADOW);
             } else {
                 need_next = true;  // miss (world.rs:124), or no light source (world.rs:86-89): black
             }
-        } else if (mode == MODE_SHADOW) {
-            const RtSurface *s = S.surfaces + h_leaf;
-            bool in_shadow = best.leaf >= 0 && best.t < h_dist;  // world.rs:145-148
-            V3 eye = -h_dir;
-            V3 surface = lighting<STATS>(s, S.light, h_point, eye, h_normal, in_shadow, ctr);
-            acc = acc + surface * w;
-
-            const double reflectivity = s->reflectivity;
-            const double transparency = s->transparency;
-            bool do_reflect = remaining != 0 && reflectivity != 0.0;   // world.rs:156-162
-            bool do_refract = remaining != 0 && transparency != 0.0;   // world.rs:175-181
-            double cos_i = dot(eye, h_normal);
-            // n1/n2 as Intersection::prepare_computations leaves them when handed the one-element list [self]
-            // (intersections.rs:41-43,66-103): n1 = 1.0, n2 = the hit object's refractive index; a non-finite t
-            // fails float_equal(t, t) and leaves both at 1.0.
-            const double n1 = 1.0;
-            const double n2 = (fabs(h_t - h_t) < EPS) ? s->refractive_index : 1.0;
-            V3 refr_dir = mk(0.0, 0.0, 0.0);
-            if (do_refract) {  // world.rs:183-194
-                ctr.add(C_REFRACT_SETUPS);
-                double n_ratio = n1 / n2;
-                double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
-                if (sin2_t > 1.0) {
-                    do_refract = false;
-                } else {
-                    double cos_t = sqrt(1.0 - sin2_t);
-                    refr_dir = h_normal * (n_ratio * cos_i - cos_t) - eye * n_ratio;
-                }
-            }
-            double w_reflect = w * reflectivity;
-            double w_refract = w * transparency;
-            if (reflectivity > 0.0 && transparency > 0.0) {  // world.rs:105-108, intersections.rs:123-136
-                ctr.add(C_SCHLICK);
-                double c = cos_i;
-                double reflectance;
-                bool total = false;
-                if (n1 > n2) {
-                    double n = n1 / n2;
-                    double sin2_t = (n * n) * (1.0 - c * c);
-                    if (sin2_t > 1.0) total = true;
-                    c = sqrt(1.0 - sin2_t);
-                }
-                if (total) {
-                    reflectance = 1.0;
-                } else {
-                    double q = (n1 - n2) / (n1 + n2);
-                    double r0 = q * q;
-                    double m = 1.0 - c;
-                    double m2 = m * m;
-                    double m5 = m * (m2 * m2);  // powi(5)
-                    reflectance = r0 + (1.0 - r0) * m5;
-                }
-                w_reflect = w_reflect * reflectance;
-                w_refract = w_refract * (1.0 - reflectance);
-            }
-            const int child_remaining = remaining - 1;
-            if (do_refract) ctr.add(C_REFRACT);
-            if (do_reflect) {
-                ctr.add(C_REFLECT);
-                if (do_refract) {  // park the refraction ray: under_point, direction (intersections.rs:63, world.rs:194)
-                    V3 under = h_point - h_normal * EPS;
-                    stk[sp][0] = under.x; stk[sp][1] = under.y; stk[sp][2] = under.z;
-                    stk[sp][3] = refr_dir.x; stk[sp][4] = refr_dir.y; stk[sp][5] = refr_dir.z;
-                    stk[sp][6] = w_refract;
-                    stk_rem[sp] = child_remaining;
-                    sp++;
-                }
-                ro = h_point + h_normal * EPS;      // over_point (intersections.rs:62)
-                rd = reflect(h_dir, h_normal);      // reflect_vector (intersections.rs:60)
-                w = w_reflect;
-                remaining = child_remaining;
-                mode = MODE_RADIANCE;
-            } else if (do_refract) {
-                ro = h_point - h_normal * EPS;
-                rd = refr_dir;
-                w = w_refract;
-                remaining = child_remaining;
-                mode = MODE_RADIANCE;
-            } else {
-                need_next = true;
-            }
         }
         if (need_next) {
-            if (sp > 0) {
-                sp--;
-                ro = mk(stk[sp][0], stk[sp][1], stk[sp][2]);
-                rd = mk(stk[sp][3], stk[sp][4], stk[sp][5]);
-                w = stk[sp][6];
-                remaining = stk_rem[sp];
+            if (nx_rem >= 0) {
+                ro = nx_o;
+                rd = nx_d;
+                w = nx_w;
+                remaining = nx_rem;
                 mode = MODE_RADIANCE;
+                nx_rem = -1;
+                if (sp > 0) {
+                    sp--;
+                    nx_o = mk(stk[sp][0], stk[sp][1], stk[sp][2]);
+                    nx_d = mk(stk[sp][3], stk[sp][4], stk[sp][5]);
+                    nx_w = stk[sp][6];
+                    nx_rem = stk_rem[sp];
+                }
             } else {
                 mode = MODE_IDLE;
             }
         }
+#ifdef RT_TIMING
+        {
+            const long long tm2 = clock64();
+            tm_trace += tm1 - tm0;
+            tm_shade += tm2 - tm1;
+            tm_iters += 1;
+            tm_lanes += __popcll(__ballot(mode != MODE_IDLE));
+        }
+#endif
     }
+#ifdef RT_TIMING
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (wv < RT_TIMING_WAVES) {
+            g_rt_timing[wv][0] = (unsigned long long)tm_trace | ((unsigned long long)tm_shade << 32);
+            g_rt_timing[wv][1] = (unsigned long long)tm_rbegin;
+            g_rt_timing[wv][2] = (unsigned long long)tm_iters | ((unsigned long long)tm_lanes << 32);
+            g_rt_timing[wv][3] = (unsigned long long)(clock64() - tm_begin) | ((unsigned long long)(wall_clock64() - tm_rbegin) << 40);
+        }
+    }
+#endif
 }
 
 template <bool STATS>
@@ -680,14 +761,69 @@ __device__ __forceinline__ SceneK scene_k(const DeviceScene &d, int max_depth) {
     return S;
 }
 
-// Camera::render (rendering/camera.rs:56-67) for the rows of `rows`.  Workgroup = 16x16 pixels, wave = 8x8.
+// The frame is cut into 8x8 pixel tiles, one per wave, numbered row-major over the rows being rendered.
+// Tile cost classes, by what the ray through the tile's centre hits first: a launch hands out the expensive classes
+// first so that its last waves are cheap ones.
+enum { TILE_CLASSES = 5, TILE_HEADER = 8 };
+__device__ __forceinline__ unsigned image_row(const RowMap &rows, unsigned r) {
+    return rows.row_begin + (r / rows.band_rows) * rows.band_pitch + (r % rows.band_rows);
+}
+
+// One lane per tile: class 0 = the centre ray misses everything, else 1 + (reflective) + 2*(transparent).
+// scratch[c] counts the tiles of class c; scratch[TILE_HEADER + c*n_tiles ...] lists them.
+template <int NEST>
+__global__ __launch_bounds__(256) void classify_tiles_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows,
+                                                             unsigned *__restrict__ scratch) {
+    const unsigned tile = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = tile < rows.n_tiles;
+    const unsigned tiles_x = (cam.hsize + 7) >> 3;
+    unsigned x = (tile % tiles_x) * 8 + 4, r = (tile / tiles_x) * 8 + 4;
+    if (x >= cam.hsize) x = cam.hsize - 1;
+    if (r >= rows.n_rows) r = rows.n_rows - 1;
+    SceneK S = scene_k(scene, 0);
+    Ctr<false> ctr;
+    V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+    if (valid) ray_for_pixel(cam, x, image_row(rows, r), ro, rd);
+    Best best = trace<NEST, false>(S, ro, rd, valid, ctr);
+    int cls = 0;
+    if (valid && best.leaf >= 0) {
+        const RtSurface *s = S.surfaces + best.leaf;
+        cls = 1 + (s->reflectivity > 0.0 ? 1 : 0) + (s->transparency > 0.0 ? 2 : 0);
+    }
+    const unsigned lane = threadIdx.x & 63;
+    for (int c = 0; c < TILE_CLASSES; ++c) {
+        const unsigned long long mask = __ballot(valid && cls == c);
+        if (mask == 0ull) continue;
+        unsigned base = 0;
+        if (lane == (unsigned)__ffsll((long long)mask) - 1u) base = atomicAdd(scratch + c, (unsigned)__popcll(mask));
+        base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+        if (valid && cls == c)
+            scratch[TILE_HEADER + (size_t)c * rows.n_tiles + base + __popcll(mask & ((1ull << lane) - 1ull))] = tile;
+    }
+}
+
+// Camera::render (rendering/camera.rs:56-67) for the rows of `rows`: one wave per 8x8 pixel tile.
 template <bool STATS, int NEST>
 __global__ __launch_bounds__(256, 4) void render_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth,
                                                      double *__restrict__ rgb, unsigned long long *counters) {
-    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const unsigned r = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);  // row in the packed output
-    const unsigned y = rows.row_begin + (r / rows.band_rows) * rows.band_pitch + (r % rows.band_rows);
+    const unsigned lane = threadIdx.x & 63;
+    unsigned tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (rows.tile_list) {  // the tile this wave renders, from the class lists, most expensive class first
+        if (tile >= rows.n_tiles) return;
+        const unsigned RT_CONSTANT_AS *count = (const unsigned RT_CONSTANT_AS *)rows.tile_list;
+        unsigned rem = tile;
+        int c = TILE_CLASSES - 1;
+        for (; c > 0; --c) {
+            const unsigned n = count[c];
+            if (rem < n) break;
+            rem -= n;
+        }
+        tile = rows.tile_list[TILE_HEADER + (size_t)c * rows.n_tiles + rem];
+    }
+    const unsigned tiles_x = (cam.hsize + 7) >> 3;
+    const unsigned x = (tile % tiles_x) * 8 + (lane & 7);
+    const unsigned r = (tile / tiles_x) * 8 + (lane >> 3);  // row in the packed output
+    const unsigned y = image_row(rows, r);
     const bool valid = x < cam.hsize && r < rows.n_rows && y < rows.row_end;
     SceneK S = scene_k(scene, max_depth);
     Ctr<STATS> ctr;
@@ -801,24 +937,46 @@ inline unsigned blocks_for(unsigned n) { return (n + 255u) / 256u; }
 // The kernels are compiled once per nesting depth of the scene (0 = no groups at all): registers for the rays of
 // levels a scene does not have are never allocated, and a flat scene carries no group code.
 template <bool STATS>
-static void launch_render_nest(int nest, dim3 grid, hipStream_t stream, const DeviceScene &scene, const RtCameraDev &camera,
+static void launch_render_nest(int nest, dim3 grid, unsigned block, hipStream_t stream, const DeviceScene &scene, const RtCameraDev &camera,
                                const RowMap &rows, int max_depth, double *rgb, unsigned long long *counters) {
     switch (nest) {
-        case 0: render_kernel<STATS, 0><<<grid, 256, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
-        case 1: render_kernel<STATS, 1><<<grid, 256, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
-        case 2: render_kernel<STATS, 2><<<grid, 256, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
-        default: render_kernel<STATS, RT_MAX_GROUP_NESTING><<<grid, 256, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
+        case 0: render_kernel<STATS, 0><<<grid, block, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
+        case 1: render_kernel<STATS, 1><<<grid, block, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
+        case 2: render_kernel<STATS, 2><<<grid, block, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
+        default: render_kernel<STATS, RT_MAX_GROUP_NESTING><<<grid, block, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
     }
 }
 
-hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows, int max_depth,
-                         double *rgb, unsigned long long *counters, hipStream_t stream) {
-    if (rows.n_rows == 0 || camera.hsize == 0 || rows.band_rows == 0) return hipSuccess;
-    dim3 grid((camera.hsize + 15) / 16, (rows.n_rows + 15) / 16);
+size_t render_scratch_words(uint32_t hsize, uint32_t n_rows) {
+    return TILE_HEADER + (size_t)TILE_CLASSES * ((hsize + 7) / 8) * ((n_rows + 7) / 8);
+}
+
+hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows_in, int max_depth,
+                         double *rgb, unsigned long long *counters, uint32_t *tile_scratch, hipStream_t stream) {
+    if (rows_in.n_rows == 0 || camera.hsize == 0 || rows_in.band_rows == 0) return hipSuccess;
+    const unsigned long long tiles = (unsigned long long)((camera.hsize + 7) / 8) * ((rows_in.n_rows + 7) / 8);
+    if (tiles > 0x7fffffffull) return hipErrorInvalidValue;
+    RowMap rows = rows_in;
+    rows.n_tiles = (unsigned)tiles;
+    if (tile_scratch) {
+        hipError_t e = hipMemsetAsync(tile_scratch, 0, TILE_HEADER * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        const dim3 cgrid(blocks_for(rows.n_tiles));
+        switch (scene.max_nesting) {
+            case 0: classify_tiles_kernel<0><<<cgrid, 256, 0, stream>>>(scene, camera, rows, tile_scratch); break;
+            case 1: classify_tiles_kernel<1><<<cgrid, 256, 0, stream>>>(scene, camera, rows, tile_scratch); break;
+            case 2: classify_tiles_kernel<2><<<cgrid, 256, 0, stream>>>(scene, camera, rows, tile_scratch); break;
+            default: classify_tiles_kernel<RT_MAX_GROUP_NESTING><<<cgrid, 256, 0, stream>>>(scene, camera, rows, tile_scratch); break;
+        }
+        rows.tile_list = tile_scratch;
+    }
+    // One wave per workgroup: a finished wave's slot is refilled at once, without waiting for three more.
+    const dim3 grid(rows.n_tiles);
+    const unsigned block = 64;
     if (counters)
-        launch_render_nest<true>(scene.max_nesting, grid, stream, scene, camera, rows, max_depth, rgb, counters);
+        launch_render_nest<true>(scene.max_nesting, grid, block, stream, scene, camera, rows, max_depth, rgb, counters);
     else
-        launch_render_nest<false>(scene.max_nesting, grid, stream, scene, camera, rows, max_depth, rgb, nullptr);
+        launch_render_nest<false>(scene.max_nesting, grid, block, stream, scene, camera, rows, max_depth, rgb, nullptr);
     return hipGetLastError();
 }
 

@@ -26,12 +26,18 @@ struct RowMap {
     uint32_t row_begin = 0, row_end = 0;
     uint32_t n_rows = 0;
     uint32_t band_rows = 1, band_pitch = 0;
+    uint32_t n_tiles = 0;                 // set by launch_render
+    const uint32_t *tile_list = nullptr;  // set by launch_render
 };
 
+// Number of 32-bit words of device scratch launch_render needs for a frame of hsize x n_rows pixels.
+size_t render_scratch_words(uint32_t hsize, uint32_t n_rows);
 // Camera::render over the rows of `rows`: rgb receives n_rows*hsize*3 doubles.
 // counters == nullptr launches the plain kernel; otherwise the counting variant adds into counters[RT_NUM_COUNTERS].
+// tile_scratch (render_scratch_words() words, or nullptr) lets the launch order its 8x8 pixel tiles by expected cost,
+// expensive first, which shortens the under-occupied end of the launch; the image does not depend on it.
 hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows, int max_depth,
-                         double *rgb, unsigned long long *counters, hipStream_t stream);
+                         double *rgb, unsigned long long *counters, uint32_t *tile_scratch, hipStream_t stream);
 // World::color_at for n rays.
 hipError_t launch_color_at(const DeviceScene &scene, const double *rays, uint32_t n, int remaining, double *colors,
                            unsigned long long *counters, hipStream_t stream);

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): phase timing of the render kernel from a library built with -DRT_TIMING.
+
+    RT_AMD_LIB=tools/bin/timing.so python tools/timing.py [scene.toml] [width] [height]
+"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import raytracer_rs_amd as rt  # noqa: E402
+from raytracer_rs_amd import _lib  # noqa: E402
+
+
+def main():
+    scene_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "scenes", "chapter_11.toml")
+    w = int(sys.argv[2]) if len(sys.argv) > 2 else 3840
+    h = int(sys.argv[3]) if len(sys.argv) > 3 else 2160
+    sf = rt.SceneFile.from_file(scene_path)
+    scene = sf.build_world().scene()
+    cam = sf.build_camera(w, h)
+    lib = _lib.lib()
+    import numpy as np
+
+    n_waves = ((w + 7) // 8) * ((h + 7) // 8)
+    buf = np.zeros((n_waves, 4), dtype=np.uint64)
+    scene.render(cam)
+    img, st = scene.render(cam)
+    lib.rt_debug_timing(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(n_waves))
+    m32, m40 = np.uint64(0xFFFFFFFF), np.uint64((1 << 40) - 1)
+    trace, shade = (buf[:, 0] & m32).astype(float), (buf[:, 0] >> np.uint64(32)).astype(float)
+    life, rlife = (buf[:, 3] & m40).astype(float), (buf[:, 3] >> np.uint64(40)).astype(float)
+    rbegin = buf[:, 1].astype(np.int64)
+    rend = rbegin + rlife.astype(np.int64)
+    span = (rend.max() - rbegin.min()) / 100.0  # us, 100 MHz constant clock
+    print(f"shader clock = {life.sum() / rlife.sum() * 100:.0f} MHz; first wave start to last wave end {span:.0f} us; "
+          f"sum of wave lifetimes {rlife.sum() / 100:.0f} us = {rlife.sum() / 100 / span:.0f} waves resident on average")
+    order = np.argsort(rbegin)
+    late = order[-4096:]
+    print(f"last 4096 waves to start: mean lifetime {rlife[late].mean() / 100:.0f} us, they start {(rbegin[late].min() - rbegin.min()) / 100:.0f} us in; "
+          f"last wave ends {(rend.max() - rbegin.min()) / 100:.0f} us in; 99% of waves have ended by {(np.sort(rend)[int(0.99 * len(rend))] - rbegin.min()) / 100:.0f} us")
+    hist_t = np.linspace(rbegin.min(), rend.max(), 21)
+    res = [int(((rbegin <= t) & (rend > t)).sum()) for t in hist_t]
+    print("resident waves over time:", res)
+    iters = (buf[:, 2] & np.uint64(0xFFFFFFFF)).astype(float)
+    lanes = (buf[:, 2] >> np.uint64(32)).astype(float)
+    print(f"kernel {st.kernel_ms:.3f} ms; waves {n_waves}; iterations/wave {iters.mean():.2f} (max {iters.max():.0f}); "
+          f"active lanes/iteration {lanes.sum() / iters.sum():.1f}")
+    print(f"per wave: lifetime {life.mean():.0f} clk (max {life.max():.0f}), trace {trace.mean():.0f} clk, shade {shade.mean():.0f} clk")
+    print(f"per iteration: trace {trace.sum() / iters.sum():.0f} clk, shade {shade.sum() / iters.sum():.0f} clk")
+    tiles_x = (w + 7) // 8
+    rows = life.reshape(-1, tiles_x).mean(axis=1)
+    step = max(1, len(rows) // 18)
+    print("mean wave lifetime by tile row (top to bottom):", " ".join(f"{rows[i:i + step].mean() / 1000:.0f}k" for i in range(0, len(rows), step)))
+
+
+if __name__ == "__main__":
+    main()
