@@ -195,7 +195,9 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     sc->dev.surfaces = sc->d_surfaces;
     sc->dev.n_nodes = (int32_t)sc->flat.nodes.size();
     sc->dev.n_leaves = (int32_t)sc->flat.surfaces.size();
+    // range-skip nodes need the kernels that fetch whole node records, i.e. those built for at least one group level
     sc->dev.max_nesting = (int32_t)sc->flat.max_nesting;
+    if (sc->flat.n_skip_nodes && sc->dev.max_nesting < 1) sc->dev.max_nesting = 1;
     sc->dev.light = sc->flat.light;
     *out = sc.release();
     return RT_OK;
@@ -216,7 +218,7 @@ void rt_scene_destroy(rt_scene *scene) {
 int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out) {
     if (!scene || !out) return set_error(RT_ERR_INVALID_ARGUMENT, "scene and out must not be NULL");
     std::memset(out, 0, sizeof *out);
-    out->n_objects = (uint32_t)scene->flat.nodes.size();
+    out->n_objects = (uint32_t)(scene->flat.nodes.size() - scene->flat.n_skip_nodes);
     out->n_leaves = scene->flat.n_leaves;
     out->n_groups = scene->flat.n_groups;
     out->max_nesting = scene->flat.max_nesting;

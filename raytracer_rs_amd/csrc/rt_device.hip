@@ -89,6 +89,28 @@ __device__ __forceinline__ double magnitude(V3 a) { return sqrt(a.x * a.x + a.y 
 // core/tuples.rs:54-56: self - (normal * 2.0) * self.dot(normal)
 __device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (n * 2.0) * dot(v, n); }
 
+// v / m for a vector and its own magnitude (Tuple::normalize, core/tuples.rs:39-47; also the three divisions by
+// `distance` in World::is_shadowed).  The compiler expands every f64 division into the same 11-instruction sequence:
+// scale, reciprocal, two Newton steps, quotient, remainder, correction, fix-up.  The reciprocal and its refinement
+// depend on the denominator only, so the three divisions share them here; quotient, remainder and correction are the
+// hardware sequence's own steps and give its (correctly rounded) result bit for bit whenever that sequence would not
+// rescale its operands -- which the exponent test on m guarantees for any component that is zero or within 2^-450 of
+// m.  A -0.0 component comes out as +0.0.  Anything else takes the plain divisions.
+__device__ __forceinline__ V3 div_by_magnitude(V3 v, double m) {
+    const unsigned biased = ((unsigned)__double2hiint(m) >> 20) - 523u;  // sign bit set (never for a magnitude) fails too
+    if (biased < 1000u) {  // 2^-500 <= m < 2^500
+        double r = __builtin_amdgcn_rcp(m);
+        double e = __builtin_fma(-m, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-m, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        double qx = v.x * r, qy = v.y * r, qz = v.z * r;
+        double rx = __builtin_fma(-m, qx, v.x), ry = __builtin_fma(-m, qy, v.y), rz = __builtin_fma(-m, qz, v.z);
+        return mk(__builtin_fma(rx, r, qx), __builtin_fma(ry, r, qy), __builtin_fma(rz, r, qz));
+    }
+    return mk(v.x / m, v.y / m, v.z / m);
+}
+
 // Matrix4 * Point / Vector (core/matrices.rs:195-221) on rows 0..2 of an affine matrix.  The point form adds
 // row[3]*1.0 == row[3]; the vector form would add row[3]*0.0, which can only change the sign of an exact zero and
 // is left out.
@@ -331,28 +353,68 @@ __device__ __forceinline__ void to_local(const NodeRaw &r, int xform, V3 o, V3 d
     }
 }
 
+// Range-skip test: may the reference find a hit with 0 <= t <= limit among objects inside the box `bb`?
+//
+// The box is padded on the host by RT_SKIP_PAD of its half-extent, which covers all rounding and the one place where
+// the reference accepts a hit slightly outside a bounded shape: a cube axis with |d| < EPSILON is treated as parallel
+// (cubes.rs:47-53), so the accepted point may sit up to EPSILON*t outside the slab.  That grows with t, hence the
+// guard: `reach` bounds the distance from the ray origin to any point of the box, dmax = max|d_i|, so every hit in it
+// has t <= reach / (0.99 dmax); culling is allowed only while EPSILON*t stays under the padding.  (Cones that take the
+// reference's linear shortcut are dealt with by the caller: no box bounds those hits.)  `inv` = 1/d per axis, by the
+// approximate reciprocal.  A NaN limit (no hit yet) rejects nothing; 0 * inf = NaN drops out of v_max_f64 / v_min_f64.
+constexpr double SKIP_REACH = 500.0;  // EPSILON * 500 / 0.99 < RT_SKIP_PAD / 1.9
+__device__ __forceinline__ bool box_may_hit(const double (&bb)[6], V3 o, V3 inv, double dmax, double limit) {
+    const double x0 = bb[0] - o.x, x1 = bb[3] - o.x, y0 = bb[1] - o.y, y1 = bb[4] - o.y, z0 = bb[2] - o.z, z1 = bb[5] - o.z;
+    const double reach = fmax(fmax(fmax(fabs(x0), fabs(x1)), fmax(fabs(y0), fabs(y1))), fmax(fabs(z0), fabs(z1)));
+    const double ax = x0 * inv.x, bx = x1 * inv.x, ay = y0 * inv.y, by = y1 * inv.y, az = z0 * inv.z, bz = z1 * inv.z;
+    const double tmin = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+    const double tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+    // a negative t is never a hit (Intersection::hit), and neither is one beyond the closest hit so far
+    const bool out = (tmin > tmax) | (tmax < -1e-6) | (tmin > limit * (1.0 + 1e-9) + 1e-9);
+    return !(out & (reach <= SKIP_REACH * dmax));
+}
+
 // World::intersect / collect_intersections (rendering/world.rs:27-78) over the node range [begin,end) at nesting
 // level D of a scene whose deepest level is NEST, for the lanes with `active` set.  begin, end and the running index
-// are wave-uniform.  Per node: take the ray into the node's space (this uses up the matrix), request the following
+// are wave-uniform.  `far`: hits beyond it do not matter to the caller (range-skip nodes use it; the t parameter is
+// the same in every space because directions are never renormalised).  Per node: take the ray into the node's space (this uses up the matrix), request the following
 // record into the registers the matrix occupied, then run the shape or bounds test while that request is in flight.
 template <int D, int NEST, bool STATS>
-__device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end, V3 o, V3 d, bool active, Best &best,
-                                            Ctr<STATS> &ctr) {
+__device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end, V3 o, V3 d, bool active, double far,
+                                            Best &best, Ctr<STATS> &ctr) {
     constexpr bool WIDE = NEST > 0;
     if (begin >= end) return;
     NodeRaw raw = node_fetch<WIDE>(S.nodes + begin);
     // Consume one word of the first record here, so that its arrival is awaited before the loop and not at the top
     // of every iteration (where the wait would also cover the request for the following record).
     asm volatile("" ::"s"(raw.b[8]));
+    V3 inv_d = mk(0.0, 0.0, 0.0);  // for range-skip nodes, computed at the first one met at this level
+    double dmax = 0.0;
+    bool have_inv = false;
     int i = begin;
     while (i < end) {
         const int tag = uniform(raw.b[8]), xform = uniform(raw.b[9]), leaf = uniform(raw.b[10]), skip = uniform(raw.b[11]);
         const int kind = tag & 0xff;
         const double a0 = dwords_to_double(raw.b[12], raw.b[13]), a1 = dwords_to_double(raw.b[14], raw.b[15]);
-        V3 lo, ld;
-        to_local(raw, xform, o, d, lo, ld);
+        // Everything that reads the first 96 bytes of the record happens before the next record is requested.
+        V3 lo = o, ld = d;
+        bool shortcut = false;  // a cone below this range-skip node takes the reference's linear shortcut for this ray
+        if (WIDE && kind == RT_SKIPBOX) {
+            if constexpr (WIDE && !STATS) {
+                if (xform == RT_SKIP_CONES) {
+                    double m[7];
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) m[k] = dwords_to_double(raw.a[2 * k], raw.a[2 * k + 1]);
+                    const double qdd = (m[0] * d.x + m[1] * d.y + m[2] * d.z) * d.x + (m[1] * d.x + m[3] * d.y + m[4] * d.z) * d.y +
+                                       (m[2] * d.x + m[4] * d.y + m[5] * d.z) * d.z;
+                    shortcut = !(fabs(qdd) >= m[6]);
+                }
+            }
+        } else {
+            to_local(raw, xform, o, d, lo, ld);
+        }
         double bb[6];
-        if constexpr (D < NEST) {
+        if constexpr (WIDE) {
             bb[0] = a0;
             bb[1] = a1;
 #pragma unroll
@@ -360,7 +422,17 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
         }
         NodeRaw nraw = node_fetch<WIDE>(S.nodes + i + 1);  // the table has one spare record at its end
         int ni = i + 1;
-        if (D < NEST && kind == RT_GROUP) {
+        if (WIDE && kind == RT_SKIPBOX) {
+            if constexpr (WIDE && !STATS) {  // the counting kernel visits everything the reference visits
+                if (!have_inv) {
+                    inv_d = mk(__builtin_amdgcn_rcp(d.x), __builtin_amdgcn_rcp(d.y), __builtin_amdgcn_rcp(d.z));
+                    dmax = fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z));
+                    have_inv = true;
+                }
+                const bool may = active && (shortcut || box_may_hit(bb, o, inv_d, dmax, fmin(best.t, far)));
+                if (__ballot(may) == 0ull) ni = skip;
+            }
+        } else if (D < NEST && kind == RT_GROUP) {
             if constexpr (D < NEST) {
                 bool inside = false;
                 if (active) {
@@ -368,13 +440,13 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
                     ctr.add(C_XFORM);
                     ctr.add(C_AABB);
                 }
-                if (__ballot(inside) != 0ull) trace_range<D + 1, NEST, STATS>(S, i + 1, skip, lo, ld, inside, best, ctr);
+                if (__ballot(inside) != 0ull) trace_range<D + 1, NEST, STATS>(S, i + 1, skip, lo, ld, inside, far, best, ctr);
                 ni = skip;
             }
         } else if (kind != RT_GROUP) {
             // Lanes that are not `active` run the test too (there is no cheaper way to idle them) but cannot
-            // change their closest hit.
-            // At the top level the inactive lanes are the ones whose result nobody reads: no mask needed there.
+            // change their closest hit.  At the top level the inactive lanes are the ones whose result nobody
+            // reads: no mask needed there.
             const bool on = D == 0 ? true : active;
             bool any;
             switch (kind) {
@@ -401,12 +473,12 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
 }
 
 template <int NEST, bool STATS>
-__device__ __forceinline__ Best trace(const SceneK &S, V3 o, V3 d, bool active, Ctr<STATS> &ctr) {
+__device__ __forceinline__ Best trace(const SceneK &S, V3 o, V3 d, bool active, double far, Ctr<STATS> &ctr) {
     Best best;
     best.t = __builtin_nan("");
     best.leaf = -1;
     if (STATS && active) ctr.add(C_RAYS);
-    trace_range<0, NEST, STATS>(S, 0, S.n_nodes, o, d, active, best, ctr);
+    trace_range<0, NEST, STATS>(S, 0, S.n_nodes, o, d, active, far, best, ctr);
     return best;
 }
 
@@ -445,7 +517,7 @@ __device__ __forceinline__ V3 normal_at(const RtSurface *s, V3 world_point) {
     V3 lp = mul_point(s->inv_world, world_point);
     V3 ln = local_normal_at(s->kind, s->minimum, s->maximum, lp);
     V3 wn = mul_vector_transposed(s->inv_world, ln);
-    return wn / magnitude(wn);
+    return div_by_magnitude(wn, magnitude(wn));
 }
 
 // Pattern::color_at (scene/patterns.rs:81-135); `%` on f64 is fmod, `as i32` saturates (v_cvt_i32_f64 does too)
@@ -484,6 +556,9 @@ __device__ __forceinline__ double powi_small(double x, unsigned n) {
     return r;
 }
 constexpr double POWI_MAX = 4096.0;
+// The general case, out of line: inlined, its two dozen polynomial constants are hoisted into registers that the
+// whole render loop then has to carry (or spill).
+__device__ __attribute__((noinline)) double pow_general(double x, double y) { return pow(x, y); }
 
 // Material::lighting (scene/materials.rs:122-172) with Pattern::color_at_object (scene/patterns.rs:137-146), evaluated
 // BEFORE the shadow ray is traced: returns the result for in_shadow = true in `shadowed` (ambient only: the reference
@@ -505,7 +580,7 @@ __device__ __forceinline__ void lighting(const RtSurface *s, const RtLight &ligh
     V3 lp = mk(light.position[0], light.position[1], light.position[2]);
     V3 effective = mk(color.x * li.x, color.y * li.y, color.z * li.z);
     V3 lv = lp - point;
-    lv = lv / magnitude(lv);
+    lv = div_by_magnitude(lv, magnitude(lv));
     V3 ambient = effective * s->ambient;
     double ldn = dot(lv, normal);
     shadowed = ambient;
@@ -523,7 +598,7 @@ __device__ __forceinline__ void lighting(const RtSurface *s, const RtLight &ligh
             double factor;
             const bool small_int = shininess >= 0.0 && shininess <= POWI_MAX && floor(shininess) == shininess;
             if (small_int) factor = powi_small(rde, (unsigned)shininess);
-            else factor = pow(rde, shininess);
+            else factor = pow_general(rde, shininess);
             specular = (li * s->specular) * factor;
         }
         lit = (ambient + diffuse) + specular;
@@ -539,7 +614,7 @@ __device__ __forceinline__ void ray_for_pixel(const RtCameraDev &cam, unsigned p
     V3 pixel = mul_point(cam.inv, mk(wx, wy, -1.0));
     origin = mk(cam.origin[0], cam.origin[1], cam.origin[2]);
     V3 v = pixel - origin;
-    dir = v / magnitude(v);
+    dir = div_by_magnitude(v, magnitude(v));
 }
 
 enum { MODE_IDLE = 0, MODE_RADIANCE = 1, MODE_SHADOW = 2 };
@@ -599,7 +674,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
 #endif
     while (__ballot(mode != MODE_IDLE) != 0ull) {
         RT_TIC(tm0);
-        Best best = trace<NEST, STATS>(S, ro, rd, mode != MODE_IDLE, ctr);
+        Best best = trace<NEST, STATS>(S, ro, rd, mode != MODE_IDLE, mode == MODE_SHADOW ? h_dist : (double)INFINITY, ctr);
         RT_TIC(tm1);
         bool need_next = false;
         if (mode == MODE_SHADOW) {
@@ -691,7 +766,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
                 double distance = magnitude(v);
                 h_dist = distance;
                 ro = over;
-                rd = v / distance;
+                rd = div_by_magnitude(v, distance);
                 mode = MODE_SHADOW;
                 ctr.add(C_SHADOW);
             } else {
@@ -784,7 +859,7 @@ __global__ __launch_bounds__(256) void classify_tiles_kernel(DeviceScene scene, 
     Ctr<false> ctr;
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     if (valid) ray_for_pixel(cam, x, image_row(rows, r), ro, rd);
-    Best best = trace<NEST, false>(S, ro, rd, valid, ctr);
+    Best best = trace<NEST, false>(S, ro, rd, valid, (double)INFINITY, ctr);
     int cls = 0;
     if (valid && best.leaf >= 0) {
         const RtSurface *s = S.surfaces + best.leaf;
@@ -879,7 +954,7 @@ __global__ __launch_bounds__(256) void intersect_kernel(DeviceScene scene, const
         ro = mk(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]);
         rd = mk(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
     }
-    Best best = trace<RT_MAX_GROUP_NESTING, false>(S, ro, rd, valid, ctr);
+    Best best = trace<RT_MAX_GROUP_NESTING, false>(S, ro, rd, valid, (double)INFINITY, ctr);
     if (valid) {
         t[i] = best.leaf >= 0 ? best.t : __builtin_nan("");
         object[i] = best.leaf >= 0 ? S.surfaces[best.leaf].object : -1;
@@ -899,9 +974,9 @@ __global__ __launch_bounds__(256) void is_shadowed_kernel(DeviceScene scene, con
         ro = mk(points[i * 3 + 0], points[i * 3 + 1], points[i * 3 + 2]);
         V3 v = mk(S.light.position[0], S.light.position[1], S.light.position[2]) - ro;  // world.rs:136-138
         distance = magnitude(v);
-        rd = v / distance;
+        rd = div_by_magnitude(v, distance);
     }
-    Best best = trace<RT_MAX_GROUP_NESTING, false>(S, ro, rd, valid && lit_world, ctr);
+    Best best = trace<RT_MAX_GROUP_NESTING, false>(S, ro, rd, valid && lit_world, distance, ctr);
     if (valid) out[i] = (lit_world && best.leaf >= 0 && best.t < distance) ? 1 : 0;
 }
 

@@ -22,13 +22,22 @@ enum { RT_XFORM_GENERAL = 0, RT_XFORM_DIAGONAL = 1 /* scale + translation */, RT
 
 struct RtNode {
     double inv[12];   // rows 0..2 of inverse(transformation), row-major 3x4
-    int32_t tag;      // RT_SPHERE .. RT_GROUP in bits 0..7; bit 8: cylinder / cone is closed
+    int32_t tag;      // RT_SPHERE .. RT_GROUP or RT_SKIPBOX in bits 0..7; bit 8: cylinder / cone is closed
     int32_t xform;    // RT_XFORM_*
     int32_t leaf;     // index into RtSurface[], -1 for groups
     int32_t skip;     // index of the first node after this node's subtree
-    double a[6];      // group: bounds min.xyz, max.xyz (in the group's own space); leaf: a[0]=minimum, a[1]=maximum
+    double a[6];      // group: bounds min.xyz, max.xyz (in the group's own space); leaf: a[0]=minimum, a[1]=maximum;
+                      // range-skip node: box min.xyz, max.xyz
 };
 #define RT_NODE_CLOSED 0x100
+// A node kind of this table only (the reference has no such object): a conservative box, in the space of the
+// sibling list it stands in, around the nodes (i, skip).  When no ray of a wave can touch the box the traversal
+// continues at `skip`; otherwise at i + 1, with the same ray.  Its matrix is the identity and it has no leaf.
+#define RT_SKIPBOX 6
+#define RT_SKIP_PAD 0.01  /* padding of such a box, as a fraction of its half-extent per axis */
+// RtNode.xform of a range-skip node: RT_SKIP_CONES when cones lie below it; then inv[0..5] is the symmetric matrix q
+// (xx, xy, xz, yy, yz, zz) and inv[6] the bound: a ray with |d^T q d| < inv[6] must not be culled (see rt_flatten.cpp).
+enum { RT_SKIP_PLAIN = 1, RT_SKIP_CONES = 3 };
 
 struct RtSurface {
     double inv_world[12];  // rows 0..2 of inverse(world_transformation)

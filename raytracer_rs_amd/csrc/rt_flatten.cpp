@@ -6,6 +6,8 @@
 //   - inverse(world_transformation) per leaf      (rendering/objects.rs:87-102)
 //   - inverse(pattern.transform) per pattern      (scene/patterns.rs:140-144)
 //   - Group::bounds() per group                   (geometry/groups.rs:130-149)
+// Added on top (no counterpart in the reference): range-skip nodes, conservative boxes around runs of consecutive
+// siblings that let the traversal step over a whole run no ray of the wave can touch.
 // A matrix the reference would fail to invert at render time (`expect("... should be invertible")`) is reported
 // here as RT_ERR_NOT_INVERTIBLE instead of aborting.
 #include "rt_flatten.hpp"
@@ -51,11 +53,92 @@ Bounds leaf_bounds(const rt_object_desc &o) {
     }
 }
 
+// Range-skip nodes (see RT_SKIPBOX in rt_device_types.h): sibling lists longer than SKIP_MIN_LIST are cut into
+// runs, recursively, until a run has at most SKIP_RUN members; every run of two or more bounded siblings gets a node.
+// Short lists are left alone: a test per node is cheaper than the wider record fetch and the extra branches.
+constexpr size_t SKIP_MIN_LIST = 12;
+constexpr size_t SKIP_RUN = 6;
+
+// The directions for which some cone below a node takes the shortcut of cones.rs:66-78: with a = dx^2 - dy^2 + dz^2
+// of the ray in the cone's space below EPSILON, the reference accepts t = -c / (2 b) -- a point that need not lie on
+// the cone or anywhere near it -- whenever that point's y is within the cone's limits.  No bounding box is
+// conservative for such a ray, so a range-skip node must let it through.  In the space of a sibling list,
+// a = lambda * d^T q d with q the unit-norm symmetric matrix A^T diag(1,-1,1) A (A = linear part of the chain of
+// inverses down to the cone) and lambda > 0.  A node can carry one q: cones whose q's agree (same axis and
+// proportions, any size -- every cone of a typical scene) share it; otherwise `ok` is false and the run gets no node.
+struct ConeDirs {
+    bool any = false, ok = true;
+    double q[6] = {0, 0, 0, 0, 0, 0};  // xx, xy, xz, yy, yz, zz
+    double lambda_min = 0.0;
+
+    static ConeDirs of_cone(const Matrix4 *inv) {
+        ConeDirs c;
+        c.any = true;
+        if (!inv) {
+            c.ok = false;
+            return c;
+        }
+        double Q[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Q[i][j] = inv->d[0][i] * inv->d[0][j] - inv->d[1][i] * inv->d[1][j] + inv->d[2][i] * inv->d[2][j];
+        c.set(Q, 1.0);
+        return c;
+    }
+    void set(const double Q[3][3], double lambda) {
+        double n = 0.0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) n += Q[i][j] * Q[i][j];
+        n = std::sqrt(n);
+        if (!(n > 0.0) || !std::isfinite(n)) {
+            ok = false;
+            return;
+        }
+        q[0] = Q[0][0] / n; q[1] = Q[0][1] / n; q[2] = Q[0][2] / n; q[3] = Q[1][1] / n; q[4] = Q[1][2] / n; q[5] = Q[2][2] / n;
+        lambda_min = lambda * n;
+    }
+    // the same set of directions seen from the parent of a group whose inverse transformation is `inv`
+    ConeDirs through(const Matrix4 *inv) const {
+        ConeDirs c = *this;
+        if (!any || !ok) return c;
+        if (!inv) {
+            c.ok = false;
+            return c;
+        }
+        const double S[3][3] = {{q[0], q[1], q[2]}, {q[1], q[3], q[4]}, {q[2], q[4], q[5]}};
+        double Q[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double v = 0.0;
+                for (int k = 0; k < 3; ++k)
+                    for (int l = 0; l < 3; ++l) v += inv->d[k][i] * S[k][l] * inv->d[l][j];
+                Q[i][j] = v;
+            }
+        c.set(Q, lambda_min);
+        return c;
+    }
+    void merge(const ConeDirs &o) {
+        if (!o.any) return;
+        if (!any) {
+            *this = o;
+            return;
+        }
+        if (!o.ok) ok = false;
+        if (!ok) return;
+        for (int i = 0; i < 6; ++i)
+            if (std::fabs(q[i] - o.q[i]) > 1e-9) ok = false;
+        lambda_min = std::fmin(lambda_min, o.lambda_min);
+    }
+};
+
 struct Builder {
     const rt_world_desc &world;
     FlatScene &out;
     std::string &err;
     int code = RT_OK;
+    // per object, from measure(): Shape::bounds() in its own space, the same in its parent's space, its children
+    std::vector<Bounds> own, in_parent;
+    std::vector<ConeDirs> cones;  // per object, in its parent's space
+    std::vector<std::vector<uint32_t>> kids;
 
     bool fail(int c, const char *fmt, unsigned idx) {
         char buf[160];
@@ -65,14 +148,120 @@ struct Builder {
         return false;
     }
 
-    // Appends object `idx` and its subtree; returns its Shape::bounds() (in its own space) through `bounds` and the
-    // index of the next sibling through `next`.
-    bool build(uint32_t idx, uint32_t depth, Bounds &bounds, uint32_t &next) {
+    // Pass 1: structure and bounds of object `idx` and its subtree; `next` = index of its next sibling.
+    bool measure(uint32_t idx, uint32_t depth, uint32_t &next) {
         if (idx >= world.n_objects) return fail(RT_ERR_INVALID_ARGUMENT, "object list ends inside the group before object #%u", idx);
         const rt_object_desc &o = world.objects[idx];
         if (o.kind < RT_SPHERE || o.kind > RT_GROUP) return fail(RT_ERR_INVALID_ARGUMENT, "object #%u has an unknown kind", idx);
         if (depth > out.max_nesting) out.max_nesting = depth;
+        if (o.kind == RT_GROUP) {
+            if (o.n_children < 0) return fail(RT_ERR_INVALID_ARGUMENT, "group #%u has a negative child count", idx);
+            Bounds gb = Bounds::empty();
+            uint32_t child = idx + 1;
+            for (int32_t k = 0; k < o.n_children; ++k) {
+                if (child >= world.n_objects) return fail(RT_ERR_INVALID_ARGUMENT, "object list ends inside group #%u", idx);
+                uint32_t after = 0;
+                if (!measure(child, depth + 1, after)) return false;
+                kids[idx].push_back(child);
+                gb = gb.merge(in_parent[child]);  // groups.rs:143-145
+                child = after;
+            }
+            own[idx] = gb;
+            next = child;
+        } else {
+            own[idx] = leaf_bounds(o);
+            next = idx + 1;
+        }
+        const Matrix4 T = Matrix4::from_array(o.transformation);
+        if (o.kind == RT_CONE || (o.kind == RT_GROUP && !kids[idx].empty())) {
+            const auto Tinv = T.inverse();
+            if (o.kind == RT_CONE) {
+                cones[idx] = ConeDirs::of_cone(Tinv ? &*Tinv : nullptr);
+            } else {
+                ConeDirs below;
+                for (uint32_t k : kids[idx]) below.merge(cones[k]);
+                cones[idx] = below.through(Tinv ? &*Tinv : nullptr);
+            }
+        }
+        in_parent[idx] = own[idx].transform(T);
+        return true;
+    }
 
+    // A conservative box around siblings list[a..b), or false when there is none worth testing.
+    bool skip_box(const std::vector<uint32_t> &list, size_t a, size_t b, double box[6], ConeDirs &dirs) const {
+        Bounds u = Bounds::empty();
+        dirs = ConeDirs{};
+        for (size_t k = a; k < b; ++k) {
+            u = u.merge(in_parent[list[k]]);
+            dirs.merge(cones[list[k]]);
+        }
+        if (dirs.any && !dirs.ok) return false;
+        const double lo[3] = {u.min.x, u.min.y, u.min.z}, hi[3] = {u.max.x, u.max.y, u.max.z};
+        for (int i = 0; i < 3; ++i) {
+            if (!std::isfinite(lo[i]) || !std::isfinite(hi[i]) || lo[i] > hi[i]) return false;
+            // what the device's range-skip test assumes (box_may_hit in rt_device.hip)
+            const double pad = RT_SKIP_PAD * 0.5 * (hi[i] - lo[i]) + 1e-7 * std::fmax(std::fabs(lo[i]), std::fabs(hi[i])) + 1e-9;
+            box[i] = lo[i] - pad;
+            box[3 + i] = hi[i] + pad;
+        }
+        return true;
+    }
+
+    void push_skip(const double box[6], const ConeDirs &dirs) {
+        RtNode head;
+        std::memset(&head, 0, sizeof head);
+        head.tag = RT_SKIPBOX;
+        head.xform = RT_SKIP_PLAIN;
+        if (dirs.any) {  // inv[0..5] = q, inv[6] = bound on |d^T q d| below which the node lets a ray through
+            head.xform = RT_SKIP_CONES;
+            for (int i = 0; i < 6; ++i) head.inv[i] = dirs.q[i];
+            head.inv[6] = 2.0 * 1e-5 / dirs.lambda_min;  // twice EPSILON (core/floats.rs:2) / lambda
+        }
+        head.leaf = -1;
+        for (int i = 0; i < 6; ++i) head.a[i] = box[i];
+        out.nodes.push_back(head);
+        out.n_skip_nodes++;
+    }
+
+    // Pass 2: emits siblings list[a..b) in order, wrapping sub-ranges of long lists in range-skip nodes.
+    bool emit_range(const std::vector<uint32_t> &list, size_t a, size_t b, uint32_t depth, bool whole_list = false) {
+        const size_t n = b - a;
+        if (n <= (whole_list ? SKIP_MIN_LIST : SKIP_RUN)) {
+            for (size_t k = a; k < b; ++k) {
+                // A member whose own test is expensive next to a box test (a group: ray transform + six divisions;
+                // cube, cylinder, cone: ray transform + a long intersection routine) gets a node of its own in
+                // front -- except in the short lists of a scene without groups, which keeps the lean kernel.
+                const int kind = world.objects[list[k]].kind;
+                double box[6];
+                ConeDirs dirs;
+                const bool wrap = (!whole_list || out.max_nesting >= 1) && kind != RT_SPHERE && kind != RT_PLANE && skip_box(list, k, k + 1, box, dirs);
+                const size_t ni = out.nodes.size();
+                if (wrap) push_skip(box, dirs);
+                if (!emit(list[k], depth)) return false;
+                if (wrap) out.nodes[ni].skip = (int32_t)out.nodes.size();
+            }
+            return true;
+        }
+        const size_t parts = n > 4 * SKIP_RUN ? 4 : 2;
+        for (size_t p = 0; p < parts; ++p) {
+            const size_t pa = a + n * p / parts, pb = a + n * (p + 1) / parts;
+            double box[6];
+            ConeDirs dirs;
+            if (pb - pa >= 2 && skip_box(list, pa, pb, box, dirs)) {
+                const size_t ni = out.nodes.size();
+                push_skip(box, dirs);
+                if (!emit_range(list, pa, pb, depth)) return false;
+                out.nodes[ni].skip = (int32_t)out.nodes.size();
+            } else if (!emit_range(list, pa, pb, depth)) {
+                return false;
+            }
+        }
+        return true;
+    }
+
+    // Appends object `idx` and its subtree.
+    bool emit(uint32_t idx, uint32_t depth) {
+        const rt_object_desc &o = world.objects[idx];
         Matrix4 T = Matrix4::from_array(o.transformation);
         auto Tinv = T.inverse();
         if (!Tinv) return fail(RT_ERR_NOT_INVERTIBLE, o.kind == RT_GROUP ? "group transformation should be invertible (object #%u)"
@@ -89,25 +278,13 @@ struct Builder {
         }
 
         if (o.kind == RT_GROUP) {
-            if (o.n_children < 0) return fail(RT_ERR_INVALID_ARGUMENT, "group #%u has a negative child count", idx);
             out.n_groups++;
-            Bounds gb = Bounds::empty();
-            uint32_t child = idx + 1;
-            for (int32_t k = 0; k < o.n_children; ++k) {
-                if (child >= world.n_objects) return fail(RT_ERR_INVALID_ARGUMENT, "object list ends inside group #%u", idx);
-                Matrix4 child_T = Matrix4::from_array(world.objects[child].transformation);
-                Bounds cb;
-                uint32_t after = 0;
-                if (!build(child, depth + 1, cb, after)) return false;
-                gb = gb.merge(cb.transform(child_T));  // groups.rs:143-145
-                child = after;
-            }
+            if (!emit_range(kids[idx], 0, kids[idx].size(), depth + 1, true)) return false;
+            const Bounds &gb = own[idx];
             RtNode &n = out.nodes[ni];
             n.a[0] = gb.min.x; n.a[1] = gb.min.y; n.a[2] = gb.min.z;
             n.a[3] = gb.max.x; n.a[4] = gb.max.y; n.a[5] = gb.max.z;
             n.skip = (int32_t)out.nodes.size();
-            bounds = gb;
-            next = child;
             return true;
         }
 
@@ -141,8 +318,6 @@ struct Builder {
         n.skip = (int32_t)ni + 1;
         out.surfaces.push_back(s);
         out.n_leaves++;
-        bounds = leaf_bounds(o);
-        next = idx + 1;
         return true;
     }
 };
@@ -155,13 +330,18 @@ int flatten_world(const rt_world_desc &world, FlatScene &out, std::string &err) 
         err = "rt_world_desc.objects is NULL";
         return RT_ERR_INVALID_ARGUMENT;
     }
-    out.nodes.reserve(world.n_objects);
+    out.nodes.reserve(world.n_objects + world.n_objects / 2);
     Builder b{world, out, err};
+    b.own.resize(world.n_objects);
+    b.in_parent.resize(world.n_objects);
+    b.kids.resize(world.n_objects);
+    b.cones.resize(world.n_objects);
+    std::vector<uint32_t> top;
     uint32_t idx = 0;
     while (idx < world.n_objects) {
-        Bounds ignored;
         uint32_t next = 0;
-        if (!b.build(idx, 0, ignored, next)) return b.code;
+        if (!b.measure(idx, 0, next)) return b.code;
+        top.push_back(idx);
         idx = next;
     }
     if (out.max_nesting > RT_MAX_GROUP_NESTING) {
@@ -171,6 +351,7 @@ int flatten_world(const rt_world_desc &world, FlatScene &out, std::string &err) 
         err = buf;
         return RT_ERR_UNSUPPORTED;
     }
+    if (!b.emit_range(top, 0, top.size(), 0, true)) return b.code;
     out.light.has_light = world.has_light ? 1 : 0;
     for (int i = 0; i < 3; ++i) {
         out.light.position[i] = world.light_position[i];

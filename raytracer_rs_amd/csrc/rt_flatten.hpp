@@ -15,6 +15,7 @@ struct FlatScene {
     RtLight light{};
     uint32_t n_groups = 0;
     uint32_t n_leaves = 0;
+    uint32_t n_skip_nodes = 0;  // range-skip nodes added to the table (not objects of the world)
     uint32_t max_nesting = 0;  // deepest nesting level of any node (top-level objects are level 0)
 };
 

@@ -278,6 +278,8 @@ def test_random_scene_matches_oracle(gpu, rt, orc, seed):
     ref = orc.render(ocam, oworld, threads=8, counters=oc)
     assert_frames_match(orc, img, ref)
     counters_equal(st, oc)
+    plain, _ = world.scene().render(cam)
+    assert np.array_equal(plain, img), "counting and plain kernels disagree"
 
 
 def test_large_generated_scene_matches_oracle(gpu, rt, orc):
@@ -297,6 +299,94 @@ def test_large_generated_scene_matches_oracle(gpu, rt, orc):
     ref = orc.render(ocam, oworld, threads=16, counters=oc)
     assert_frames_match(orc, img, ref)
     counters_equal(st, oc)
+    # the plain kernel steps over runs of nodes no ray of a wave can touch; the counting kernel visits everything
+    plain, _ = world.scene().render(cam)
+    assert np.array_equal(plain, img), "counting and plain kernels disagree"
+
+
+def _lone_rays_agree(orc, scene, oworld, rays):
+    """Every ray alone in its wave (64 copies of it): nothing another lane needs keeps a skipped run alive."""
+    t, obj = scene.intersect(np.repeat(rays, 64, axis=0))
+    t, obj = t.reshape(-1, 64), obj.reshape(-1, 64)
+    assert (obj == obj[:, :1]).all()
+    for k, ray in enumerate(rays):
+        hit = oworld.hit(orc.ray(ray[:3], ray[3:]))
+        if hit is None:
+            assert obj[k, 0] == -1, (k, ray, obj[k, 0], t[k, 0])
+        else:
+            assert (obj[k, 0], t[k, 0]) == (hit[1], hit[0]), (k, ray, (obj[k, 0], t[k, 0]), hit)
+
+
+def _probe_rays(orc, ocam, seed, n_camera, n_random, box):
+    rng = np.random.default_rng(seed)
+    rays = []
+    for _ in range(n_camera):
+        r = orc.ray_for_pixel(ocam, int(rng.integers(0, ocam.hsize)), int(rng.integers(0, ocam.vsize)))
+        rays.append(list(r.origin.tuple()) + list(r.direction.tuple()))
+    lo, hi = np.array(box[0], dtype=float), np.array(box[1], dtype=float)
+    o = rng.uniform(lo, hi, size=(n_random, 3))
+    d = rng.normal(size=(n_random, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([np.array(rays), np.concatenate([o, d], axis=1)])
+
+
+def test_range_skipping_never_loses_a_hit(gpu, rt, orc):
+    """Closest hits of lone rays (camera rays and rays from random points in random directions) in the scenes whose
+    node tables carry range-skip nodes: the 10 001-leaf hierarchy and chapter_14's hexagons."""
+    import tomli
+
+    from raytracer_rs_amd import synthetic
+
+    text = synthetic.large_scene(320, 180)
+    sf = rt.SceneFile.from_str(text)
+    ocam, oworld = orc.scene_from_dict(tomli.loads(text))
+    rays = _probe_rays(orc, ocam, 21, 300, 500, ((-21, 0.05, -21), (21, 3, 21)))
+    _lone_rays_agree(orc, sf.build_world().scene(), oworld, rays)
+
+    cam, world, ocam, oworld = load_both(rt, orc, "chapter_14", 200, 100)
+    rays = _probe_rays(orc, ocam, 22, 300, 500, ((-3, -1, -3), (3, 3, 3)))
+    _lone_rays_agree(orc, world.scene(), oworld, rays)
+
+
+def test_cone_linear_shortcut_survives_range_skipping(gpu, rt, orc):
+    """A ray with dx^2 - dy^2 + dz^2 below EPSILON in a cone's space: the reference takes t = -c / (2 b)
+    (cones.rs:66-78), a point well off the cone and outside its bounding box, and accepts it because its y lies
+    within the cone's limits.  Such a ray must get past every range-skip node above that cone."""
+    import tomli
+
+    from raytracer_rs_amd import synthetic
+
+    text = synthetic.large_scene(320, 180)
+    sf = rt.SceneFile.from_str(text)
+    _, oworld = orc.scene_from_dict(tomli.loads(text))
+    # met as a fifth-generation ray of pixel (1301, 586) of the 1920x1080 frame
+    ray = np.array([[3.66955354, 0.42627462, -4.58568923, 0.70703312, -0.70710699, -0.01019148]])
+    hit = oworld.hit(orc.ray(ray[0, :3], ray[0, 3:]))
+    assert hit is not None
+    _lone_rays_agree(orc, sf.build_world().scene(), oworld, ray)
+    # and a family of them: rays at 45 degrees to the axes of a row of unbounded-radius cones with y limits -1..1,
+    # alternating with cubes, in one group; origins far outside the row on both sides
+    w = rt.World()
+    ow = orc.World()
+    w.light_source = rt.PointLight((-10, 10, -10), (1, 1, 1))
+    ow.set_light((-10, 10, -10), (1, 1, 1))
+    g = rt.Object.group()
+    og = ow.add(orc.GROUP, orc.identity())
+    for k in range(20):
+        kind, okind = (rt.CONE, orc.CONE) if k % 2 else (rt.CUBE, orc.CUBE)
+        g.add_child(rt.Object(kind, transformation=rt.Matrix4.translate(3.0 * k, 0, 0), minimum=-1.0, maximum=1.0))
+        ow.add(okind, orc.translate(3.0 * k, 0, 0), None, og, -1.0, 1.0, False)
+    w.objects = [g]
+    ow.finalize()
+    rays = []
+    for k in range(1, 20, 2):
+        for off in (-40.0, -7.5, 2.5, 9.0, 33.0):
+            sx = 1.0 if off < 0 else -1.0
+            # reaches y = 0.25 above the cone at x = 3k after |off| / (S2/2) along the ray
+            rays.append([3.0 * k + off, 0.25 + abs(off), 0.3, sx * S2 / 2, -S2 / 2, 0.0])
+    rays = np.array(rays)
+    assert sum(ow.hit(orc.ray(r[:3], r[3:])) is not None for r in rays) >= 10
+    _lone_rays_agree(orc, w.scene(), ow, rays)
 
 
 # --------------------------------------------------------------------------- rows, bands, sizes, depth
