@@ -36,8 +36,21 @@ extern "C" int rt_debug_timing(unsigned long long *out, unsigned n_waves) {
     return e == hipSuccess ? 0 : -4;
 }
 #define RT_TIC(var) const long long var = clock64()
+__device__ unsigned long long g_rt_nodes[4];  // node records visited (wave-level), by class: skip, group, leaf
+#ifdef RT_TIMING_NODES  /* one atomic per node visit: counts are right, timings are not */
+#define RT_NODE_VISIT(k) if ((threadIdx.x & 63) == 0) atomicAdd(&g_rt_nodes[k], 1ull)
+#else
+#define RT_NODE_VISIT(k)
+#endif
+extern "C" int rt_debug_nodes(unsigned long long *out) {
+    unsigned long long zero[4] = {0};
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rt_nodes), sizeof zero);
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_rt_nodes), zero, sizeof zero);
+    return e == hipSuccess ? 0 : -4;
+}
 #else
 #define RT_TIC(var)
+#define RT_NODE_VISIT(k)
 #endif
 
 namespace rt {
@@ -69,6 +82,9 @@ struct Ctr {
 };
 template <>
 struct Ctr<false> {
+    // How many range-skip boxes and group bounds this lane's ray passed: a cost estimate that only the tile
+    // classification reads (everywhere else the increments are dead code).
+    unsigned visits = 0;
     __device__ __forceinline__ void clear() {}
     __device__ __forceinline__ void add(int) {}
 };
@@ -422,6 +438,7 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
         }
         NodeRaw nraw = node_fetch<WIDE>(S.nodes + i + 1);  // the table has one spare record at its end
         int ni = i + 1;
+        RT_NODE_VISIT(kind == RT_SKIPBOX ? 0 : kind == RT_GROUP ? 1 : 2);
         if (WIDE && kind == RT_SKIPBOX) {
             if constexpr (WIDE && !STATS) {  // the counting kernel visits everything the reference visits
                 if (!have_inv) {
@@ -430,6 +447,7 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
                     have_inv = true;
                 }
                 const bool may = active && (shortcut || box_may_hit(bb, o, inv_d, dmax, fmin(best.t, far)));
+                ctr.visits += may ? 1u : 0u;
                 if (__ballot(may) == 0ull) ni = skip;
             }
         } else if (D < NEST && kind == RT_GROUP) {
@@ -440,6 +458,7 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
                     ctr.add(C_XFORM);
                     ctr.add(C_AABB);
                 }
+                if constexpr (!STATS) ctr.visits += inside ? 4u : 0u;
                 if (__ballot(inside) != 0ull) trace_range<D + 1, NEST, STATS>(S, i + 1, skip, lo, ld, inside, far, best, ctr);
                 ni = skip;
             }
@@ -837,15 +856,15 @@ __device__ __forceinline__ SceneK scene_k(const DeviceScene &d, int max_depth) {
 }
 
 // The frame is cut into 8x8 pixel tiles, one per wave, numbered row-major over the rows being rendered.
-// Tile cost classes, by what the ray through the tile's centre hits first: a launch hands out the expensive classes
-// first so that its last waves are cheap ones.
-enum { TILE_CLASSES = 5, TILE_HEADER = 8 };
+// Tile cost classes, from the ray through the tile's centre: what it hits first (a miss costs one ray, a diffuse hit
+// two, a mirror or glass a whole tree) times how much of a deep scene it had to walk through.  Half-octave buckets
+// of that estimate; a launch hands out the expensive classes first so that its last waves are cheap ones.
+enum { TILE_CLASSES = 20, TILE_HEADER = 24 };
 __device__ __forceinline__ unsigned image_row(const RowMap &rows, unsigned r) {
     return rows.row_begin + (r / rows.band_rows) * rows.band_pitch + (r % rows.band_rows);
 }
 
-// One lane per tile: class 0 = the centre ray misses everything, else 1 + (reflective) + 2*(transparent).
-// scratch[c] counts the tiles of class c; scratch[TILE_HEADER + c*n_tiles ...] lists them.
+// One lane per tile.  scratch[c] counts the tiles of class c; scratch[TILE_HEADER + c*n_tiles ...] lists them.
 template <int NEST>
 __global__ __launch_bounds__(256) void classify_tiles_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows,
                                                              unsigned *__restrict__ scratch) {
@@ -860,11 +879,15 @@ __global__ __launch_bounds__(256) void classify_tiles_kernel(DeviceScene scene, 
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     if (valid) ray_for_pixel(cam, x, image_row(rows, r), ro, rd);
     Best best = trace<NEST, false>(S, ro, rd, valid, (double)INFINITY, ctr);
-    int cls = 0;
+    unsigned weight = 1;
     if (valid && best.leaf >= 0) {
         const RtSurface *s = S.surfaces + best.leaf;
-        cls = 1 + (s->reflectivity > 0.0 ? 1 : 0) + (s->transparency > 0.0 ? 2 : 0);
+        weight = s->transparency > 0.0 ? 12u : s->reflectivity > 0.0 ? 6u : 2u;
     }
+    const unsigned cost = weight * (8u + ctr.visits);  // >= 8
+    const int lg = 31 - __clz((int)cost);
+    int cls = 2 * (lg - 3) + (int)((cost >> (lg - 1)) & 1u);
+    if (cls > TILE_CLASSES - 1) cls = TILE_CLASSES - 1;
     const unsigned lane = threadIdx.x & 63;
     for (int c = 0; c < TILE_CLASSES; ++c) {
         const unsigned long long mask = __ballot(valid && cls == c);

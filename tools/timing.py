@@ -17,7 +17,11 @@ def main():
     scene_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "scenes", "chapter_11.toml")
     w = int(sys.argv[2]) if len(sys.argv) > 2 else 3840
     h = int(sys.argv[3]) if len(sys.argv) > 3 else 2160
-    sf = rt.SceneFile.from_file(scene_path)
+    if scene_path == "large":
+        from raytracer_rs_amd import synthetic
+        sf = rt.SceneFile.from_str(synthetic.large_scene())
+    else:
+        sf = rt.SceneFile.from_file(scene_path)
     scene = sf.build_world().scene()
     cam = sf.build_camera(w, h)
     lib = _lib.lib()
@@ -26,7 +30,11 @@ def main():
     n_waves = ((w + 7) // 8) * ((h + 7) // 8)
     buf = np.zeros((n_waves, 4), dtype=np.uint64)
     scene.render(cam)
+    nodes = (ctypes.c_ulonglong * 4)()
+    lib.rt_debug_nodes(nodes)
     img, st = scene.render(cam)
+    lib.rt_debug_nodes(nodes)
+    print("wave-level node visits (incl. the tile-ordering pass): skip %d, group %d, leaf %d" % (nodes[0], nodes[1], nodes[2]))
     lib.rt_debug_timing(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(n_waves))
     m32, m40 = np.uint64(0xFFFFFFFF), np.uint64((1 << 40) - 1)
     trace, shade = (buf[:, 0] & m32).astype(float), (buf[:, 0] >> np.uint64(32)).astype(float)
