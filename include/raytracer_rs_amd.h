@@ -184,6 +184,10 @@ size_t rt_canvas_to_ppm(const double *rgb, uint32_t width, uint32_t height, char
 int rt_canvas_write_ppm(const double *rgb, uint32_t width, uint32_t height, const char *path);
 /* convert_canvas_color_value_to_decimal_rgb_value (rendering/canvas.rs:123-130) over n values. */
 int rt_canvas_quantize(const double *rgb, size_t n, uint8_t *out);
+/* The same over a frame still in device memory (both pointers are device pointers on the current device),
+ * asynchronously on `stream` (a hipStream_t; NULL = the null stream): 8-bit frames are what a PPM needs and an
+ * eighth of the bytes to move between GPUs or to the host. */
+int rt_canvas_quantize_device(const double *rgb_device, size_t n, uint8_t *out_device, void *stream);
 
 /* SceneFile::from_file (scenes/loader.rs:190-194): reads and parses a TOML scene. */
 int rt_scene_file_load(const char *path, rt_scene_file **out);

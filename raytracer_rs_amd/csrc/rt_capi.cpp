@@ -424,6 +424,12 @@ int rt_ray_for_pixel(const rt_camera_desc *camera, const uint32_t *px, const uin
     return RT_OK;
 }
 
+int rt_canvas_quantize_device(const double *rgb_device, size_t n, uint8_t *out_device, void *stream) {
+    if ((!rgb_device || !out_device) && n) return set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(rt::launch_quantize(rgb_device, n, out_device, (hipStream_t)stream));
+    return RT_OK;
+}
+
 int rt_camera_new(uint32_t hsize, uint32_t vsize, double field_of_view, rt_camera_desc *out) {
     if (!out) return set_error(RT_ERR_INVALID_ARGUMENT, "out must not be NULL");
     rt::camera_new(hsize, vsize, field_of_view, *out);

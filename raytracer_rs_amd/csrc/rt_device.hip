@@ -97,7 +97,6 @@ __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y +
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ V3 operator/(V3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
 // core/tuples.rs:59-61
 __device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // core/tuples.rs:35-37
@@ -532,8 +531,10 @@ __device__ __forceinline__ V3 local_normal_at(int kind, double minimum, double m
 }
 
 // Object::normal_at (rendering/objects.rs:171-184)
-__device__ __forceinline__ V3 normal_at(const RtSurface *s, V3 world_point) {
+// `object_point` = world_to_object(world_point) (objects.rs:87-91), which Pattern::color_at_object needs again.
+__device__ __forceinline__ V3 normal_at(const RtSurface *s, V3 world_point, V3 &object_point) {
     V3 lp = mul_point(s->inv_world, world_point);
+    object_point = lp;
     V3 ln = local_normal_at(s->kind, s->minimum, s->maximum, lp);
     V3 wn = mul_vector_transposed(s->inv_world, ln);
     return div_by_magnitude(wn, magnitude(wn));
@@ -584,11 +585,10 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y) { re
 // adds black diffuse and specular terms, which changes nothing) and the result for in_shadow = false in `lit`.
 // `flags` bit 0: the diffuse branch is taken when not in shadow; bit 1: powf is evaluated then.
 template <bool STATS>
-__device__ __forceinline__ void lighting(const RtSurface *s, const RtLight &light, V3 point, V3 eye, V3 normal,
-                                         V3 &shadowed, V3 &lit, int &flags, Ctr<STATS> &ctr) {
+__device__ __forceinline__ void lighting(const RtSurface *s, const RtLight &light, V3 point, V3 object_point, V3 eye,
+                                         V3 normal, V3 &shadowed, V3 &lit, int &flags, Ctr<STATS> &ctr) {
     V3 color;
     if (s->pattern_kind != RT_PATTERN_NONE) {
-        V3 object_point = mul_point(s->inv_world, point);
         V3 pattern_point = mul_point(s->pat_inv, object_point);
         color = pattern_color(s, pattern_point);
         ctr.add(C_PATTERNS);
@@ -711,14 +711,15 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
                 // Intersection::prepare_computations (rendering/intersections.rs:45-63)
                 const RtSurface *s = S.surfaces + best.leaf;
                 V3 point = ro + rd * best.t;
-                V3 normal = normal_at(s, point);
+                V3 object_point;
+                V3 normal = normal_at(s, point, object_point);
                 V3 eye = -rd;
                 if (dot(normal, eye) < 0.0) normal = -normal;
                 V3 over = point + normal * EPS;
                 ctr.add(C_SHADES);
 
                 V3 shadowed, lit;
-                lighting<STATS>(s, S.light, point, eye, normal, shadowed, lit, h_flags, ctr);
+                lighting<STATS>(s, S.light, point, object_point, eye, normal, shadowed, lit, h_flags, ctr);
                 acc_lit = acc + lit * w;
                 acc = acc + shadowed * w;
 
@@ -1010,8 +1011,9 @@ __global__ __launch_bounds__(256) void normal_at_kernel(DeviceScene scene, const
     if (i >= n) return;
     int l = leaf[i];
     V3 r = mk(__builtin_nan(""), __builtin_nan(""), __builtin_nan(""));
+    V3 object_point;
     if (l >= 0 && l < scene.n_leaves)
-        r = normal_at(scene.surfaces + l, mk(points[i * 3 + 0], points[i * 3 + 1], points[i * 3 + 2]));
+        r = normal_at(scene.surfaces + l, mk(points[i * 3 + 0], points[i * 3 + 1], points[i * 3 + 2]), object_point);
     normals[i * 3 + 0] = r.x;
     normals[i * 3 + 1] = r.y;
     normals[i * 3 + 2] = r.z;
@@ -1026,6 +1028,29 @@ __global__ __launch_bounds__(256) void ray_for_pixel_kernel(RtCameraDev cam, con
     ray_for_pixel(cam, px[i], py[i], o, d);
     rays[i * 6 + 0] = o.x; rays[i * 6 + 1] = o.y; rays[i * 6 + 2] = o.z;
     rays[i * 6 + 3] = d.x; rays[i * 6 + 4] = d.y; rays[i * 6 + 5] = d.z;
+}
+
+// convert_canvas_color_value_to_decimal_rgb_value (rendering/canvas.rs:123-130) over a frame that is still in device
+// memory: (value * 255.0).round() as u32, then min(255).  `round` is half-away-from-zero; the Rust cast saturates and
+// maps NaN to 0.  Eight values per lane: 64 B loaded, 8 B stored, both contiguous across the wave.
+__global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict__ rgb, size_t n, uint8_t *__restrict__ out) {
+    const size_t base = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (base >= n) return;
+    unsigned q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double v = base + k < n ? rgb[base + k] : 0.0;
+        const double r = round(v * 255.0);
+        q[k] = !(r > 0.0) ? 0u : r >= 255.0 ? 255u : (unsigned)r;
+    }
+    if (base + 8 <= n && (reinterpret_cast<size_t>(out + base) & 7) == 0) {
+        uint2 w;
+        w.x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+        w.y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+        *reinterpret_cast<uint2 *>(out + base) = w;
+    } else {
+        for (int k = 0; k < 8 && base + k < n; ++k) out[base + k] = (uint8_t)q[k];
+    }
 }
 
 inline unsigned blocks_for(unsigned n) { return (n + 255u) / 256u; }
@@ -1110,6 +1135,13 @@ hipError_t launch_normal_at(const DeviceScene &scene, const int32_t *leaf, const
                             double *normals, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     normal_at_kernel<<<blocks_for(n), 256, 0, stream>>>(scene, leaf, points, n, normals);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize(const double *rgb, size_t n, uint8_t *out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const size_t per_block = 256 * 8;
+    quantize_kernel<<<(unsigned)((n + per_block - 1) / per_block), 256, 0, stream>>>(rgb, n, out);
     return hipGetLastError();
 }
 

@@ -38,6 +38,8 @@ size_t render_scratch_words(uint32_t hsize, uint32_t n_rows);
 // expensive first, which shortens the under-occupied end of the launch; the image does not depend on it.
 hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows, int max_depth,
                          double *rgb, unsigned long long *counters, uint32_t *tile_scratch, hipStream_t stream);
+// The canvas quantiser (rendering/canvas.rs:123-130) over n values in device memory.
+hipError_t launch_quantize(const double *rgb, size_t n, uint8_t *out, hipStream_t stream);
 // World::color_at for n rays.
 hipError_t launch_color_at(const DeviceScene &scene, const double *rays, uint32_t n, int remaining, double *colors,
                            unsigned long long *counters, hipStream_t stream);

@@ -135,6 +135,7 @@ struct Builder {
     FlatScene &out;
     std::string &err;
     int code = RT_OK;
+    Builder(const rt_world_desc &w, FlatScene &o, std::string &e) : world(w), out(o), err(e) {}
     // per object, from measure(): Shape::bounds() in its own space, the same in its parent's space, its children
     std::vector<Bounds> own, in_parent;
     std::vector<ConeDirs> cones;  // per object, in its parent's space
@@ -331,7 +332,7 @@ int flatten_world(const rt_world_desc &world, FlatScene &out, std::string &err) 
         return RT_ERR_INVALID_ARGUMENT;
     }
     out.nodes.reserve(world.n_objects + world.n_objects / 2);
-    Builder b{world, out, err};
+    Builder b(world, out, err);
     b.own.resize(world.n_objects);
     b.in_parent.resize(world.n_objects);
     b.kids.resize(world.n_objects);

@@ -79,6 +79,60 @@ def test_gpu_reproduces_reference_ppm(gpu, rt, scene, image):
     assert hashlib.sha256(canvas.to_ppm_string()).hexdigest() == sha
 
 
+def test_command_line_renderer_writes_the_reference_ppm(gpu, tmp_path):
+    """rt_render stands in for the reference's main(): scene file in, byte-identical PPM out."""
+    import hashlib
+    import json
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "raytracer_rs_amd", "rt_render")
+    out = tmp_path / "chapter_6_sphere.ppm"
+    done = subprocess.run([exe, scene_path("chapter_6"), "-o", str(out), "--stats"], capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0, done.stderr
+    assert "rays" in done.stdout
+    with open(os.path.join(GOLDEN, "MANIFEST.json")) as f:
+        sha = json.load(f)["ppm"]["chapter_6_sphere"]["sha256_p3_text"]
+    assert hashlib.sha256(out.read_bytes()).hexdigest() == sha
+    bad = subprocess.run([exe, str(tmp_path / "missing.toml")], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 1 and "missing.toml" in bad.stderr
+
+
+def test_device_quantiser_matches_host(gpu, rt):
+    """canvas.rs:123-130 on a frame in device memory: ties away from zero, saturation, NaN -> 0."""
+    import ctypes
+
+    from raytracer_rs_amd import _lib
+
+    rng = np.random.default_rng(3)
+    vals = np.concatenate([rng.uniform(-0.2, 1.3, size=100003), np.arange(0, 256) / 255.0, (np.arange(0, 256) + 0.5) / 255.0,
+                           np.nextafter((np.arange(0, 256) + 0.5) / 255.0, -1.0),
+                           [0.0, -0.0, 1.0, 2.0, -1.0, np.nan, np.inf, -np.inf, 1e300, -1e300, 0.5 / 255.0, 254.5 / 255.0]])
+    expect = np.zeros(vals.size, dtype=np.uint8)
+    lib = _lib.lib()
+    _lib.check(lib.rt_canvas_quantize(vals.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), vals.size,
+                                      expect.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library itself is linked against
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d_in), vals.nbytes) == 0 and hip.hipMalloc(ctypes.byref(d_out), vals.size + 16) == 0
+    try:
+        assert hip.hipMemcpy(d_in, vals.ctypes.data_as(ctypes.c_void_p), vals.nbytes, 1) == 0  # host to device
+        for offset in (0, 1, 5):  # the output need not be 8-byte aligned
+            assert hip.hipMemset(d_out, 0, vals.size + 16) == 0
+            _lib.check(lib.rt_canvas_quantize_device(d_in, vals.size, ctypes.c_void_p(d_out.value + offset), None))
+            assert hip.hipDeviceSynchronize() == 0
+            got = np.zeros(vals.size + 16, dtype=np.uint8)
+            assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), d_out, got.size, 2) == 0  # device to host
+            assert np.array_equal(got[offset:offset + vals.size], expect)
+            assert not got[:offset].any() and not got[offset + vals.size:].any()
+    finally:
+        hip.hipFree(d_in)
+        hip.hipFree(d_out)
+
+
 # --------------------------------------------------------------------------- the reference's unit tests, on the GPU
 def close(a, b, eps=1e-5):
     return all(abs(x - y) < eps for x, y in zip(a, b))

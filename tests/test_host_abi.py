@@ -280,3 +280,15 @@ def test_loader_matches_on_generated_scenes(rt, orc):
         assert wd.n_objects == oworld.object_count()
         for i in range(wd.n_objects):
             assert list(wd.objects[i].world_transformation) == [v for row in oworld.world_transform(i).rows() for v in row]
+
+
+def test_command_line_renderer_usage(rt):
+    """No GPU needed: argument errors are reported before anything touches a device."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "raytracer_rs_amd", "rt_render")
+    assert os.path.exists(exe), "rt_render has not been built (make -C raytracer_rs_amd/csrc)"
+    done = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert done.returncode == 2 and "usage: rt_render" in done.stderr
+    done = subprocess.run([exe, "a.toml", "--width", "10"], capture_output=True, text=True, timeout=60)
+    assert done.returncode == 2
