@@ -102,6 +102,9 @@ def main() -> None:
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frame", choices=["f64", "u8"], default="f64",
+                    help="what rank 0 collects: the f64 canvas (the reference's Canvas.pixels; default) or the 8-bit "
+                         "frame a PPM is written from, quantised on each GPU before the gather (an eighth of the bytes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,13 +124,21 @@ def main() -> None:
     scene = world.scene(local_rank)
     W, H = cam.hsize, cam.vsize
     # device buffers: my bands (padded to equal size so the gather is uniform) and, on rank 0, the frame
-    bg = BandGather(W, H, rank, world_size, dev, BAND_ROWS)
+    u8 = args.frame == "u8"
+    bg = BandGather(W, H, rank, world_size, dev, BAND_ROWS, dtype=torch.uint8 if u8 else torch.float64)
     stream = torch.cuda.current_stream().cuda_stream
+    # with 8-bit collection the kernel still writes f64 colours; they are quantised in place of the gather's input
+    target = bg.frame if world_size == 1 else bg.mine
+    f64_out = torch.zeros(target.shape, dtype=torch.float64, device=dev) if u8 else target
 
     def render_mine(stats: bool = False):
         if world_size == 1:
-            return scene.render_device(cam, bg.frame.data_ptr(), None, 0, stream, stats)
-        return scene.render_device_bands(cam, bg.mine.data_ptr(), BAND_ROWS, rank, world_size, 0, stream, stats)
+            st = scene.render_device(cam, f64_out.data_ptr(), None, 0, stream, stats)
+        else:
+            st = scene.render_device_bands(cam, f64_out.data_ptr(), BAND_ROWS, rank, world_size, 0, stream, stats)
+        if u8:
+            rt.quantize_device(f64_out.data_ptr(), f64_out.numel(), target.data_ptr(), stream)
+        return st
 
     def step():
         render_mine()
@@ -202,7 +213,7 @@ def main() -> None:
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{os.path.basename(args.scene)} at {W}x{H}, depth 5, {BAND_ROWS}-row bands "
-                                   f"round-robin over {world_size} GPU(s), f64 frame gathered to rank 0",
+                                   f"round-robin over {world_size} GPU(s), {args.frame} frame gathered to rank 0",
                        "rays_per_frame": rays_frame, "rays_per_pixel": round(rays_frame / (W * H), 3),
                        "kernel_ms_max_over_ranks": round(kernel_ms_max, 4)},
             "roofline": {"bound": "valu_f64", "achieved": round(achieved_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS,

@@ -4,9 +4,9 @@
 from ._lib import (CONE, CUBE, CYLINDER, DEFAULT_DEPTH, GROUP, MAX_DEPTH, MAX_GROUP_NESTING, PATTERN_CHECKERS,
                    PATTERN_GRADIENT, PATTERN_NONE, PATTERN_RING, PATTERN_STRIPE, PLANE, SPHERE, RtError, Stats)
 from .api import (Camera, Canvas, Material, Matrix4, Object, Pattern, PointLight, Ray, Scene, SceneFile, World,
-                  view_transform)
+                  quantize_device, view_transform)
 
 __all__ = ["Camera", "Canvas", "Material", "Matrix4", "Object", "Pattern", "PointLight", "Ray", "Scene", "SceneFile",
-           "World", "view_transform", "RtError", "Stats", "SPHERE", "PLANE", "CUBE", "CYLINDER", "CONE", "GROUP",
+           "World", "view_transform", "quantize_device", "RtError", "Stats", "SPHERE", "PLANE", "CUBE", "CYLINDER", "CONE", "GROUP",
            "PATTERN_NONE", "PATTERN_STRIPE", "PATTERN_GRADIENT", "PATTERN_RING", "PATTERN_CHECKERS",
            "DEFAULT_DEPTH", "MAX_DEPTH", "MAX_GROUP_NESTING"]

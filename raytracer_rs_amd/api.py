@@ -450,6 +450,11 @@ class World:
         return bool(self.scene().is_shadowed(np.array([list(point)]))[0])
 
 
+def quantize_device(rgb_device_ptr: int, n: int, out_device_ptr: int, stream: int = 0) -> None:
+    """rt_canvas_quantize_device: canvas.rs:123-130 over n f64 values in device memory -> n bytes in device memory."""
+    L.check(L.lib().rt_canvas_quantize_device(C.c_void_p(rgb_device_ptr), n, C.c_void_p(out_device_ptr), C.c_void_p(stream)))
+
+
 class Canvas:
     """rendering/canvas.rs:7-11: width, height, pixels (row-major, 3 f64 per pixel)."""
 
