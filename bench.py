@@ -6,11 +6,13 @@
 
 A step is one whole frame.  With N ranks the frame's rows are cut into 16-row bands dealt round-robin to the ranks
 (band b -> rank b % N; band cost varies from ~1 ray/px in the sky to ~30 rays/px on the glass, and the fine interleave
-evens that out); every rank renders its bands with the HIP library into device memory and the bands are gathered to
-rank 0 with one RCCL gather (grouped send/recv over xGMI) and copied into the frame.  The scene is replicated, so the
-gather is the only collective.  The timed region starts with scene, camera and output buffers resident in HBM; it
-covers kernel + gather + placement of the bands in the frame, K times, between barrier+synchronize pairs, and rank 0
-reports the maximum over ranks.
+evens that out); every rank renders its bands with the HIP library into device memory (f64 colours), quantises them to the 8-bit
+frame a PPM is written from (canvas.rs:123-130, as a kernel; `--frame f64` keeps the f64 canvas instead), and the
+bands are gathered to rank 0 with one RCCL gather (grouped send/recv over xGMI) and copied into the frame.  The gather
+of frame k runs on its own stream and overlaps the rendering of frame k+1.  The scene is replicated, so the gather is
+the only collective.  The timed region starts with scene, camera and output buffers resident in HBM; it covers
+kernel + quantiser + gather + placement of the bands in the frame, K times, between barrier+synchronize pairs, and
+rank 0 reports the maximum over ranks.
 
 Rank 0 prints ONE JSON line.  `value` = rays of the frame (a ray = one World::intersect call of the reference:
 camera, shadow, reflection and refraction rays; counted once by the library's counting kernel) x K / time.
@@ -102,51 +104,72 @@ def main() -> None:
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frame", choices=["f64", "u8"], default="f64",
-                    help="what rank 0 collects: the f64 canvas (the reference's Canvas.pixels; default) or the 8-bit "
-                         "frame a PPM is written from, quantised on each GPU before the gather (an eighth of the bytes)")
+    ap.add_argument("--check", action="store_true",
+                    help="after the timed steps, rank 0 renders the whole frame by itself and compares the collected frame with it")
+    ap.add_argument("--frame", choices=["f64", "u8"], default="u8",
+                    help="what rank 0 collects: the 8-bit frame a PPM is written from, quantised on each GPU "
+                         "(canvas.rs:123-130) before the gather (default), or the f64 canvas itself (8x the bytes)")
     args = ap.parse_args()
 
+    if os.environ.get("RT_BENCH_WATCHDOG"):  # developer aid: dump every thread's stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal on a box with fewer GPUs than ranks (RT_BENCH_BACKEND=gloo): ranks share devices and the gather goes
+    # through gloo; the real launch is one rank per GPU over nccl (= RCCL).
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     sf = rt.SceneFile.from_file(args.scene)
     cam = sf.build_camera(args.width, args.height)
     world = sf.build_world()
-    scene = world.scene(local_rank)
+    scene = world.scene(device_index)
     W, H = cam.hsize, cam.vsize
     # device buffers: my bands (padded to equal size so the gather is uniform) and, on rank 0, the frame
     u8 = args.frame == "u8"
     bg = BandGather(W, H, rank, world_size, dev, BAND_ROWS, dtype=torch.uint8 if u8 else torch.float64)
     stream = torch.cuda.current_stream().cuda_stream
-    # with 8-bit collection the kernel still writes f64 colours; they are quantised in place of the gather's input
-    target = bg.frame if world_size == 1 else bg.mine
-    f64_out = torch.zeros(target.shape, dtype=torch.float64, device=dev) if u8 else target
+    # with 8-bit collection the kernel still writes f64 colours; they are quantised into the buffer that is collected
+    f64_stage = torch.zeros((bg.n_bands if world_size == 1 else bg.slots, bg.band_vals), dtype=torch.float64, device=dev) if u8 else None
 
-    def render_mine(stats: bool = False):
+    def render_mine(k: int = 0, stats: bool = False, events=None):
+        """Frame k: this rank's bands, rendered (and quantised) into the buffer the gather of frame k reads.
+        `events` brackets the render kernel alone."""
+        target = bg.frame if world_size == 1 else bg.buffer(k)
+        out = f64_stage if u8 else target
+        if world_size > 1:
+            bg.begin_render(k)
+        if events:
+            events[0].record()
         if world_size == 1:
-            st = scene.render_device(cam, f64_out.data_ptr(), None, 0, stream, stats)
+            st = scene.render_device(cam, out.data_ptr(), None, 0, stream, stats)
         else:
-            st = scene.render_device_bands(cam, f64_out.data_ptr(), BAND_ROWS, rank, world_size, 0, stream, stats)
+            st = scene.render_device_bands(cam, out.data_ptr(), BAND_ROWS, rank, world_size, 0, stream, stats)
+        if events:
+            events[1].record()
         if u8:
-            rt.quantize_device(f64_out.data_ptr(), f64_out.numel(), target.data_ptr(), stream)
+            rt.quantize_device(out.data_ptr(), out.numel(), target.data_ptr(), stream)
         return st
 
-    def step():
-        render_mine()
+    def step(k: int):
+        render_mine(k)
         if world_size > 1:
-            bg.gather()
+            bg.gather(k)
 
     # rays of the frame, counted once by the counting kernel (untimed)
-    st = render_mine(stats=True)
+    st = render_mine(0, stats=True)
     counts = st.as_dict()
     flat = []
     for k in rt.Stats.COUNT_FIELDS:
@@ -167,19 +190,19 @@ def main() -> None:
     rays_frame = total_counts["rays"]
     my_flops = algorithmic_flops(counts)
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
+    bg.finish()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world_size > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()
-        render_mine()
-        ev[k][1].record()
+        render_mine(k, events=ev[k])
         if world_size > 1:
-            bg.gather()
+            bg.gather(k)  # on its own stream: overlaps the rendering of frame k+1
+    bg.finish()
     if world_size > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -189,6 +212,19 @@ def main() -> None:
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms_max = t.tolist()
+
+    if args.check and rank == 0:
+        whole = torch.zeros(H * W * 3, dtype=torch.float64, device=dev)
+        scene.render_device(cam, whole.data_ptr(), None, 0, stream, False)
+        if u8:
+            q = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
+            rt.quantize_device(whole.data_ptr(), whole.numel(), q.data_ptr(), stream)
+            whole = q
+        torch.cuda.synchronize()
+        same = torch.equal(bg.frame_rows().reshape(-1), whole)
+        print(f"check: collected frame {'equals' if same else 'DIFFERS FROM'} the single-GPU frame", file=sys.stderr, flush=True)
+        if not same:
+            raise SystemExit(3)
 
     if rank == 0:
         ms_per_step = elapsed / max(1, args.steps) * 1e3
@@ -213,7 +249,9 @@ def main() -> None:
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{os.path.basename(args.scene)} at {W}x{H}, depth 5, {BAND_ROWS}-row bands "
-                                   f"round-robin over {world_size} GPU(s), {args.frame} frame gathered to rank 0",
+                                   f"round-robin over {world_size} GPU(s), f64 colours -> "
+                                   + ("8-bit frame (quantised on the GPU, as Canvas::to_ppm does) " if u8 else "f64 frame ")
+                                   + "collected on rank 0",
                        "rays_per_frame": rays_frame, "rays_per_pixel": round(rays_frame / (W * H), 3),
                        "kernel_ms_max_over_ranks": round(kernel_ms_max, 4)},
             "roofline": {"bound": "valu_f64", "achieved": round(achieved_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS,

@@ -7,7 +7,8 @@ varies by an order of magnitude between sky and glass, and a fine round-robin in
 run-time coordination between the processes.
 
 The gather is `torch.distributed.gather`, which on the NCCL/RCCL backend is a group of point-to-point send/recv:
-every peer's bands travel over that peer's own xGMI link into rank 0.
+every peer's bands travel over that peer's own xGMI link into rank 0.  It runs on its own stream and overlaps the
+rendering of the next frame (two send buffers per rank).
 """
 from __future__ import annotations
 
@@ -40,37 +41,79 @@ def band_rows_range(band: int, height: int, band_rows: int = DEFAULT_BAND_ROWS) 
 class BandGather:
     """Buffers and the collective for assembling a frame on rank 0.
 
-    `mine` is this rank's send buffer ([bands_per_rank, band_rows*width*channels]); rank 0 also owns `frame`
-    ([n_bands, band_rows*width*channels], i.e. the frame padded to whole bands; `frame_rows()` views the real rows).
+    Every rank owns `depth` send buffers ([bands_per_rank, band_rows*width*channels] each; `buffer(k)` is the one
+    frame k goes through, `mine` is buffer 0); rank 0 also owns `frame` ([n_bands, band_rows*width*channels], i.e.
+    the frame padded to whole bands; `frame_rows()` views the real rows).
+
+    On a GPU the gather of frame k runs on a stream of its own, so it overlaps the rendering of frame k+1 into the
+    other send buffer: `begin_render(k)` makes the rendering stream wait until buffer(k) is free again,
+    `gather(k)` hands the buffer over once everything queued on the rendering stream so far has finished, and
+    `finish()` joins the two streams.  On the CPU (gloo rehearsal) the same calls run one after the other.
     """
 
     def __init__(self, width: int, height: int, rank: int, world_size: int, device: torch.device,
-                 band_rows: int = DEFAULT_BAND_ROWS, channels: int = 3, dtype: torch.dtype = torch.float64):
+                 band_rows: int = DEFAULT_BAND_ROWS, channels: int = 3, dtype: torch.dtype = torch.float64,
+                 depth: int = 2):
         self.width, self.height, self.rank, self.world_size = width, height, rank, world_size
         self.band_rows, self.channels = band_rows, channels
         self.band_vals = band_rows * width * channels
         self.n_bands = n_bands(height, band_rows)
         self.slots = bands_per_rank(world_size, height, band_rows)
-        self.mine = torch.zeros(self.slots, self.band_vals, dtype=dtype, device=device)
+        self.depth = max(1, depth) if world_size > 1 else 1
+        self.send = [torch.zeros(self.slots, self.band_vals, dtype=dtype, device=device) for _ in range(self.depth)]
+        self.mine = self.send[0]
         self.frame: Optional[torch.Tensor] = None
         self._recv: Optional[List[torch.Tensor]] = None
         if rank == 0:
             self.frame = torch.zeros(self.n_bands, self.band_vals, dtype=dtype, device=device)
             if world_size > 1:
                 self._recv = [torch.empty_like(self.mine) for _ in range(world_size)]
+        self._comm = None
+        if device.type == "cuda" and world_size > 1:
+            self._comm = torch.cuda.Stream(device=device)
+            self._rendered = [torch.cuda.Event() for _ in range(self.depth)]
+            self._gathered = [torch.cuda.Event() for _ in range(self.depth)]
+            self._in_flight = [False] * self.depth
 
-    def gather(self) -> Optional[torch.Tensor]:
-        """Collects every rank's bands on rank 0 and places them in the frame.  Returns the frame on rank 0."""
+    def buffer(self, k: int = 0) -> torch.Tensor:
+        return self.send[k % self.depth]
+
+    def begin_render(self, k: int = 0) -> None:
+        """Call before rendering frame k into buffer(k)."""
+        if self._comm is not None and self._in_flight[k % self.depth]:
+            torch.cuda.current_stream().wait_event(self._gathered[k % self.depth])
+
+    def gather(self, k: int = 0) -> Optional[torch.Tensor]:
+        """Collects every rank's bands of frame k on rank 0 and places them in the frame.  Returns the frame on
+        rank 0 (on a GPU: once the work queued here has run; see finish())."""
+        src = self.buffer(k)
         if self.world_size == 1:
-            self.frame[: self.slots].copy_(self.mine)
+            self.frame[: self.slots].copy_(src)
             return self.frame
-        dist.gather(self.mine, self._recv, dst=0)
+        if self._comm is None:
+            self._gather_and_place(src)
+        else:
+            i = k % self.depth
+            self._rendered[i].record(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm):
+                self._comm.wait_event(self._rendered[i])
+                self._gather_and_place(src)
+                self._gathered[i].record(self._comm)
+            self._in_flight[i] = True
+        return self.frame if self.rank == 0 else None
+
+    def _gather_and_place(self, src: torch.Tensor) -> None:
+        dist.gather(src, self._recv, dst=0)
         if self.rank != 0:
-            return None
+            return
         for r in range(self.world_size):
             k = len(range(r, self.n_bands, self.world_size))
             self.frame[r::self.world_size] = self._recv[r][:k]
-        return self.frame
+
+    def finish(self) -> None:
+        """Makes the current stream wait for every gather queued so far."""
+        if self._comm is not None:
+            torch.cuda.current_stream().wait_stream(self._comm)
 
     def frame_rows(self) -> torch.Tensor:
         """The assembled frame as [height, width, channels] (rank 0)."""
