@@ -317,13 +317,14 @@ def test_normals_are_bit_exact(gpu, rt, orc):
 
 
 # --------------------------------------------------------------------------- generated scenes
-@pytest.mark.parametrize("seed", range(1, 13))
-def test_random_scene_matches_oracle(gpu, rt, orc, seed):
+# n_top > 12 gives the top-level list a tree of range-skip nodes on top of the per-member ones every scene with groups has
+@pytest.mark.parametrize("seed,n_top", [(s, 6) for s in range(1, 13)] + [(101, 25), (102, 40), (103, 60), (104, 90)])
+def test_random_scene_matches_oracle(gpu, rt, orc, seed, n_top):
     import tomli
 
     from raytracer_rs_amd import synthetic
 
-    text = synthetic.random_scene(seed, 96, 64)
+    text = synthetic.random_scene(seed, 96, 64, n_top)
     sf = rt.SceneFile.from_str(text)
     cam, world = sf.build_camera(), sf.build_world()
     ocam, oworld = orc.scene_from_dict(tomli.loads(text))
