@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer check (GPU box): renders every fixture scene with the HIP library and compares it with the CPU oracle.
 
-    python tools/gpu_check.py [scene ...] [--scale S]
+    python tests/devtools/gpu_check.py [scene ...] [--scale S]
 
 Prints, per scene: max |GPU - oracle| over all colour values, the number of 8-bit pixels that differ, whether the
 operation counters agree, and the kernel time.  Exit status 1 if any scene breaks the parity bar
@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import raytracer_rs_amd as rt  # noqa: E402

@@ -1,22 +1,22 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): render one perf.py configuration to a .npy, or compare two such files.
 
-    RT_AMD_LIB=... python tools/imgdiff.py render c5 /tmp/a.npy
-    python tools/imgdiff.py compare /tmp/a.npy /tmp/b.npy
+    RT_AMD_LIB=... python tests/devtools/imgdiff.py render c5 /tmp/a.npy
+    python tests/devtools/imgdiff.py compare /tmp/a.npy /tmp/b.npy
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
 def main():
     if sys.argv[1] == "render":
         import raytracer_rs_amd as rt
-        from tools.perf import SIZES, scene_text
+        from tests.devtools.perf import SIZES, scene_text
 
         name, out = sys.argv[2], sys.argv[3]
         sf = rt.SceneFile.from_str(scene_text(name))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer timing loop (GPU box): kernel milliseconds of the render kernel on the benchmark configurations.
 
-    python tools/perf.py [--reps 5] [--configs c3,c4,c5]
+    python tests/devtools/perf.py [--reps 5] [--configs c3,c4,c5]
 
 c2 = chapter_7_and_8 at 1920x1080, c3 = chapter_11 at 3840x2160 (the headline), c4 = chapter_14 at 3840x2160,
 c5 = the generated 10 000-leaf scene at 1920x1080.  Each config is also rendered at a reduced size and compared with
@@ -14,7 +14,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import raytracer_rs_amd as rt  # noqa: E402

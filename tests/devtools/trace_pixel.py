@@ -2,7 +2,7 @@
 """Developer tool (GPU box): walks the ray tree of one pixel with the CPU oracle and replays every ray (radiance and
 shadow) through the library's rt_intersect / rt_is_shadowed, printing where they disagree.
 
-    python tools/trace_pixel.py c5 1301 586
+    python tests/devtools/trace_pixel.py c5 1301 586
 """
 import os
 import sys
@@ -10,11 +10,11 @@ import sys
 import numpy as np
 import tomli
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import raytracer_rs_amd as rt  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
-from tools.perf import SIZES, scene_text  # noqa: E402
+from tests.devtools.perf import SIZES, scene_text  # noqa: E402
 
 
 def main():
