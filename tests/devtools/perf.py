@@ -51,12 +51,14 @@ def main():
         if not a.no_check:
             w, h = CHECK[name]
             cam = sf.build_camera(w, h)
-            img, st = scene.render(cam, stats=True)
+            counted, st = scene.render(cam, stats=True)  # the counting kernel visits every node
+            img, _ = scene.render(cam)                    # the timed kernel steps over runs of nodes
             ocam, oworld = orc.scene_from_dict(tomli.loads(text), w, h)
             oc = orc.Counters()
             ref = orc.render(ocam, oworld, threads=16, counters=oc)
             err = float(np.abs(img - ref).max())
-            status = f"check {w}x{h}: max|d|={err:.1e} counters={'ok' if st.as_dict() == oc.as_dict() else 'DIFFER'}"
+            status = (f"check {w}x{h}: max|d|={err:.1e} counters={'ok' if st.as_dict() == oc.as_dict() else 'DIFFER'} "
+                      f"kernels={'agree' if np.array_equal(img, counted) else 'DISAGREE'}")
         w, h = SIZES[name]
         cam = sf.build_camera(w, h)
         img, st = scene.render(cam, stats=True)
