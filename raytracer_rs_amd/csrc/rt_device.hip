@@ -64,6 +64,9 @@ constexpr double EPS = 1e-5;          // core/floats.rs:2
 constexpr double AABB_EPS = 1e-10;    // geometry/bounds.rs:114
 constexpr double CHECKER_EPS = 1e-6;  // scene/patterns.rs:106
 constexpr int STACK_MAX = RT_MAX_DEPTH + 1;  // in memory: at most one parked ray per level, plus one while a hit pushes two
+constexpr int LDS_LEVELS = 2;                // of which the first ones are kept in LDS: 2 x 64 B per lane = 8 KB per wave
+constexpr unsigned RAY_STACK_LDS_BYTES_PER_WAVE = LDS_LEVELS * 8 * 64 * sizeof(double);
+extern __shared__ double ray_stack_lds[];    // dynamic: RAY_STACK_LDS_BYTES_PER_WAVE per wave of the workgroup
 
 enum {
     C_RAYS = 0, C_PRIMARY, C_SHADOW, C_REFLECT, C_REFRACT,
@@ -661,21 +664,33 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
     int h_flags = 0;
 
     // Pending rays (origin, direction, weight, remaining budget), last in first out.  The newest one lives in
-    // registers (nx_*, valid while nx_rem >= 0), older ones in a per-lane array in scratch memory.  A pop hands out
-    // the register copy and at once asks memory for the entry below it, so that load completes during the next
-    // traversal instead of being waited for.
+    // registers (nx_*, valid while nx_rem >= 0); below it, the first LDS_LEVELS entries live in the workgroup's LDS
+    // (field-major, one 8-byte bank column per lane: conflict-free) and only deeper ones in a per-lane array in
+    // scratch memory -- scratch is interleaved across the wave's lanes, so the few lanes that push at any time
+    // dirty whole cache lines, and those lines travel to HBM.  A pop hands out the register copy and at once asks
+    // for the entry below it, so that load completes during the next traversal instead of being waited for.
     V3 nx_o = mk(0, 0, 0), nx_d = mk(0, 0, 0);
     double nx_w = 0.0;
     int nx_rem = -1;
-    double stk[STACK_MAX][7];
-    int stk_rem[STACK_MAX];
+    double *const lds = ray_stack_lds + (threadIdx.x & ~63u) * (LDS_LEVELS * 8) + (threadIdx.x & 63u);
+    double stk[STACK_MAX - LDS_LEVELS][7];
+    int stk_rem[STACK_MAX - LDS_LEVELS];
     int sp = 0;
     auto push = [&](V3 po, V3 pd, double pw, int prem) {
         if (nx_rem >= 0) {
-            stk[sp][0] = nx_o.x; stk[sp][1] = nx_o.y; stk[sp][2] = nx_o.z;
-            stk[sp][3] = nx_d.x; stk[sp][4] = nx_d.y; stk[sp][5] = nx_d.z;
-            stk[sp][6] = nx_w;
-            stk_rem[sp] = nx_rem;
+            if (sp < LDS_LEVELS) {
+                double *e = lds + sp * (8 * 64);
+                e[0 * 64] = nx_o.x; e[1 * 64] = nx_o.y; e[2 * 64] = nx_o.z;
+                e[3 * 64] = nx_d.x; e[4 * 64] = nx_d.y; e[5 * 64] = nx_d.z;
+                e[6 * 64] = nx_w;
+                e[7 * 64] = __hiloint2double(0, nx_rem);
+            } else {
+                const int d = sp - LDS_LEVELS;
+                stk[d][0] = nx_o.x; stk[d][1] = nx_o.y; stk[d][2] = nx_o.z;
+                stk[d][3] = nx_d.x; stk[d][4] = nx_d.y; stk[d][5] = nx_d.z;
+                stk[d][6] = nx_w;
+                stk_rem[d] = nx_rem;
+            }
             sp++;
         }
         nx_o = po;
@@ -803,10 +818,19 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
                 nx_rem = -1;
                 if (sp > 0) {
                     sp--;
-                    nx_o = mk(stk[sp][0], stk[sp][1], stk[sp][2]);
-                    nx_d = mk(stk[sp][3], stk[sp][4], stk[sp][5]);
-                    nx_w = stk[sp][6];
-                    nx_rem = stk_rem[sp];
+                    if (sp < LDS_LEVELS) {
+                        const double *e = lds + sp * (8 * 64);
+                        nx_o = mk(e[0 * 64], e[1 * 64], e[2 * 64]);
+                        nx_d = mk(e[3 * 64], e[4 * 64], e[5 * 64]);
+                        nx_w = e[6 * 64];
+                        nx_rem = __double2loint(e[7 * 64]);
+                    } else {
+                        const int d = sp - LDS_LEVELS;
+                        nx_o = mk(stk[d][0], stk[d][1], stk[d][2]);
+                        nx_d = mk(stk[d][3], stk[d][4], stk[d][5]);
+                        nx_w = stk[d][6];
+                        nx_rem = stk_rem[d];
+                    }
                 }
             } else {
                 mode = MODE_IDLE;
@@ -1063,10 +1087,10 @@ template <bool STATS>
 static void launch_render_nest(int nest, dim3 grid, unsigned block, hipStream_t stream, const DeviceScene &scene, const RtCameraDev &camera,
                                const RowMap &rows, int max_depth, double *rgb, unsigned long long *counters) {
     switch (nest) {
-        case 0: render_kernel<STATS, 0><<<grid, block, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
-        case 1: render_kernel<STATS, 1><<<grid, block, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
-        case 2: render_kernel<STATS, 2><<<grid, block, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
-        default: render_kernel<STATS, RT_MAX_GROUP_NESTING><<<grid, block, 0, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
+        case 0: render_kernel<STATS, 0><<<grid, block, (block / 64) * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
+        case 1: render_kernel<STATS, 1><<<grid, block, (block / 64) * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
+        case 2: render_kernel<STATS, 2><<<grid, block, (block / 64) * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
+        default: render_kernel<STATS, RT_MAX_GROUP_NESTING><<<grid, block, (block / 64) * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
     }
 }
 
@@ -1108,11 +1132,11 @@ hipError_t launch_color_at(const DeviceScene &scene, const double *rays, uint32_
     if (n == 0) return hipSuccess;
     const bool flat = scene.max_nesting == 0;
     if (counters) {
-        if (flat) color_at_kernel<true, 0><<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, remaining, colors, counters);
-        else color_at_kernel<true, RT_MAX_GROUP_NESTING><<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, remaining, colors, counters);
+        if (flat) color_at_kernel<true, 0><<<blocks_for(n), 256, 4 * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, rays, n, remaining, colors, counters);
+        else color_at_kernel<true, RT_MAX_GROUP_NESTING><<<blocks_for(n), 256, 4 * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, rays, n, remaining, colors, counters);
     } else {
-        if (flat) color_at_kernel<false, 0><<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, remaining, colors, nullptr);
-        else color_at_kernel<false, RT_MAX_GROUP_NESTING><<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, remaining, colors, nullptr);
+        if (flat) color_at_kernel<false, 0><<<blocks_for(n), 256, 4 * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, rays, n, remaining, colors, nullptr);
+        else color_at_kernel<false, RT_MAX_GROUP_NESTING><<<blocks_for(n), 256, 4 * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, rays, n, remaining, colors, nullptr);
     }
     return hipGetLastError();
 }

@@ -31,7 +31,7 @@ def main() -> None:
     with open(stats) as f:
         for row in csv.DictReader(f):
             name = row["Name"]
-            short = name.replace("void rt::(anonymous namespace)::", "").split("(")[0]
+            short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             lines.append(f"| `{short}` | {row['Calls']} | {float(row['AverageNs']) / 1e6:.4f} | {float(row['MinNs']) / 1e6:.4f} | "
                          f"{float(row['MaxNs']) / 1e6:.4f} | {float(row['Percentage']):.2f} |")
             if needle in name:
