@@ -465,6 +465,48 @@ def test_row_ranges_and_bands_tile_the_frame(gpu, rt, orc):
         scene.render(cam, rows=(50, 200))
 
 
+def test_device_buffer_entry_point_and_band_packing(gpu, rt, orc):
+    """rt_render_device: the asynchronous entry point the multi-GPU driver uses.  Rows and bands arrive packed in
+    device memory; put back in place they are the frame rt_render returns."""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    cam, world, _, _ = load_both(rt, orc, "chapter_11", 203, 77)
+    scene = world.scene()
+    full, _ = scene.render(cam)
+    W, H = cam.hsize, cam.vsize
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), full.nbytes) == 0
+    try:
+        def fetch(n_rows):
+            out = np.zeros((n_rows, W, 3))
+            assert hip.hipDeviceSynchronize() == 0
+            assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), buf, out.nbytes, 2) == 0
+            return out
+
+        scene.render_device(cam, buf.value)
+        assert np.array_equal(fetch(H), full)
+        scene.render_device(cam, buf.value, rows=(10, 45))
+        assert np.array_equal(fetch(35), full[10:45])
+        for band_rows, step in ((16, 2), (8, 3), (5, 4)):
+            for first in range(step):
+                scene.render_device_bands(cam, buf.value, band_rows, first, step)
+                bands = list(range(first, (H + band_rows - 1) // band_rows, step))
+                rows = sum(min(H, (b + 1) * band_rows) - b * band_rows for b in bands)
+                got = fetch(rows)
+                at = 0
+                for b in bands:
+                    y0, y1 = b * band_rows, min(H, (b + 1) * band_rows)
+                    # every band occupies band_rows rows of the packed buffer except that the frame's last band may be short
+                    assert np.array_equal(got[at:at + y1 - y0], full[y0:y1]), (band_rows, step, first, b)
+                    at += band_rows if y1 - y0 == band_rows else y1 - y0
+    finally:
+        hip.hipFree(buf)
+
+
 @pytest.mark.parametrize("size", [(1, 1), (17, 9), (33, 65), (64, 1), (1, 40), (250, 130)])
 def test_odd_frame_sizes(gpu, rt, orc, size):
     cam, world, ocam, oworld = load_both(rt, orc, "chapter_13", *size)
