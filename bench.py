@@ -255,7 +255,8 @@ def main() -> None:
                        "rays_per_frame": rays_frame, "rays_per_pixel": round(rays_frame / (W * H), 3),
                        "kernel_ms_max_over_ranks": round(kernel_ms_max, 4)},
             "roofline": {"bound": "valu_f64", "achieved": round(achieved_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved_tf / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": round(achieved_tf / FP64_VECTOR_PEAK_TFLOPS, 4),
+                         "frac_of_unfused_ceiling": round(2.0 * achieved_tf / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel": "render_kernel<false, 0> (kernel_ms also spans the tile-ordering pass classify_tiles_kernel<0>, "
                                    "about 1 % of it)", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_flops_per_launch": my_flops,

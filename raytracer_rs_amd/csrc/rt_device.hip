@@ -5,19 +5,20 @@
 //
 // Execution model
 //   * one lane per pixel (or per query ray); a wave of 64 lanes covers an 8x8 pixel tile so that neighbouring lanes
-//     see the same objects; 256-thread workgroups cover 16x16 pixels.
+//     see the same objects; one wave per workgroup, tiles handed out in order of estimated cost.
 //   * scene traversal is WAVE-UNIFORM: all lanes of a wave walk the node table with one scalar node index, so node
 //     records (inverse matrices, bounds, kind) arrive by scalar loads into SGPRs and the shape switch is a scalar
 //     branch.  A group's subtree is entered when ANY lane's ray passes the group's bounds (wave ballot); lanes whose
 //     own ray missed are masked for the subtree.  Each lane therefore tests exactly the primitives the reference
-//     tests for its ray, in the reference's order.
+//     tests for its ray, in the reference's order -- minus whole runs of nodes that a range-skip node (a padded box
+//     the host adds in front of long sibling lists and expensive members) proves out of reach of every lane.
 //   * the recursion of World::shade_hit / color_at (rendering/world.rs:84-126) is an iterative per-lane loop with ONE
 //     traversal call site: a lane alternates between tracing a radiance ray and tracing the shadow ray of the hit it
-//     found, so lanes whose ray missed go straight on to their next pending ray.  Secondary rays carry a scalar path
-//     weight; when a hit spawns both a reflection and a refraction ray the refraction ray is parked on a per-lane
-//     stack of at most `max_depth` entries.
-//   * no MFMA: nothing on this path is a dense contraction.  No LDS: the node table is read through the scalar
-//     cache, the per-hit surface records through the vector L1.
+//     found.  A hit is shaded for both outcomes of the shadow test before the shadow ray is traced; its reflection
+//     and refraction rays carry a scalar path weight and wait on a per-lane stack: top entry in registers, two
+//     levels in LDS, the rest in scratch.
+//   * no MFMA: nothing on this path is a dense contraction.  The node table is read through the scalar cache, the
+//     per-hit surface records through the vector L1; LDS holds only the ray stacks.
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -27,7 +28,7 @@
 #include "rt_device.hpp"
 
 #ifdef RT_TIMING
-// Developer build: per-wave shader-clock totals of the phases of radiance() (tools/timing.py reads them).
+// Developer build (-DRT_TIMING): per-wave shader-clock totals of the phases of radiance() (tools/timing.py reads them).
 #define RT_TIMING_WAVES (1 << 20)
 __device__ unsigned long long g_rt_timing[RT_TIMING_WAVES][4];  // per wave: trace | shade<<32, real-time begin, iterations, lifetime | real-time lifetime<<40
 extern "C" int rt_debug_timing(unsigned long long *out, unsigned n_waves) {
