@@ -439,7 +439,10 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
 #pragma unroll
             for (int k = 0; k < 4; ++k) bb[2 + k] = dwords_to_double(raw.c[2 * k], raw.c[2 * k + 1]);
         }
-        NodeRaw nraw = node_fetch<WIDE>(S.nodes + i + 1);  // the table has one spare record at its end
+        // The record to have ready next: the following one -- except after a range-skip node, which more often
+        // than not sends the traversal to `skip` (the table has one spare record at its end).
+        const int guess = (WIDE && kind == RT_SKIPBOX && !STATS) ? skip : i + 1;
+        NodeRaw nraw = node_fetch<WIDE>(S.nodes + guess);
         int ni = i + 1;
         RT_NODE_VISIT(kind == RT_SKIPBOX ? 0 : kind == RT_GROUP ? 1 : 2);
         if (WIDE && kind == RT_SKIPBOX) {
@@ -487,7 +490,7 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
             ni = skip;  // a group at the deepest level the scene declares: it has no children
         }
         if constexpr (NEST > 0) {
-            if (ni != i + 1) nraw = node_fetch<WIDE>(S.nodes + ni);  // the subtree was stepped over: fetch the record wanted
+            if (ni != guess) nraw = node_fetch<WIDE>(S.nodes + ni);  // guessed wrong: fetch the record wanted
         }
         raw = nraw;
         i = uniform(ni);  // every operand above is wave-uniform; keep the index in an SGPR
