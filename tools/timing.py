@@ -28,13 +28,9 @@ def main():
     import numpy as np
 
     n_waves = ((w + 7) // 8) * ((h + 7) // 8)
-    buf = np.zeros((n_waves, 4), dtype=np.uint64)
+    buf = np.zeros((n_waves, 6), dtype=np.uint64)
     scene.render(cam)
-    nodes = (ctypes.c_ulonglong * 4)()
-    lib.rt_debug_nodes(nodes)
     img, st = scene.render(cam)
-    lib.rt_debug_nodes(nodes)
-    print("wave-level node visits (incl. the tile-ordering pass): skip %d, group %d, leaf %d" % (nodes[0], nodes[1], nodes[2]))
     lib.rt_debug_timing(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(n_waves))
     m32, m40 = np.uint64(0xFFFFFFFF), np.uint64((1 << 40) - 1)
     trace, shade = (buf[:, 0] & m32).astype(float), (buf[:, 0] >> np.uint64(32)).astype(float)
@@ -57,6 +53,13 @@ def main():
           f"active lanes/iteration {lanes.sum() / iters.sum():.1f}")
     print(f"per wave: lifetime {life.mean():.0f} clk (max {life.max():.0f}), trace {trace.mean():.0f} clk, shade {shade.mean():.0f} clk")
     print(f"per iteration: trace {trace.sum() / iters.sum():.0f} clk, shade {shade.sum() / iters.sum():.0f} clk")
+    skipn, groupn, leafn = (buf[:, 4] & m32).astype(float), (buf[:, 4] >> np.uint64(32)).astype(float), buf[:, 5].astype(float)
+    nodes = skipn + groupn + leafn
+    print(f"node records per traversal (wave level): skip {skipn.sum() / iters.sum():.1f}, group {groupn.sum() / iters.sum():.1f}, "
+          f"leaf {leafn.sum() / iters.sum():.1f}; trace clocks per node {trace.sum() / max(1.0, nodes.sum()):.0f}")
+    worst = int(np.argmax(life))
+    print(f"longest wave: {iters[worst]:.0f} iterations, {lanes[worst] / iters[worst]:.1f} active lanes, {nodes[worst] / iters[worst]:.0f} nodes "
+          f"per traversal, {trace[worst] / max(1.0, nodes[worst]):.0f} trace clocks per node, lifetime {life[worst] / 1e6:.1f} Mclk")
     tiles_x = (w + 7) // 8
     rows = life.reshape(-1, tiles_x).mean(axis=1)
     step = max(1, len(rows) // 18)
