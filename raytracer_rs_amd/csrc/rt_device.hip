@@ -30,25 +30,15 @@
 #ifdef RT_TIMING
 // Developer build (-DRT_TIMING): per-wave shader-clock totals of the phases of radiance() (tools/timing.py reads them).
 #define RT_TIMING_WAVES (1 << 20)
-__device__ unsigned long long g_rt_timing[RT_TIMING_WAVES][4];  // per wave: trace | shade<<32, real-time begin, iterations, lifetime | real-time lifetime<<40
+__device__ unsigned long long g_rt_timing[RT_TIMING_WAVES][6];  // per wave: trace | shade<<32, real-time begin, iterations | lanes<<32, lifetime | real-time lifetime<<40, skip | group<<32 node visits, leaf visits
 extern "C" int rt_debug_timing(unsigned long long *out, unsigned n_waves) {
     if (n_waves > RT_TIMING_WAVES) n_waves = RT_TIMING_WAVES;
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rt_timing), (size_t)n_waves * 4 * sizeof(unsigned long long));
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rt_timing), (size_t)n_waves * 6 * sizeof(unsigned long long));
     return e == hipSuccess ? 0 : -4;
 }
 #define RT_TIC(var) const long long var = clock64()
-__device__ unsigned long long g_rt_nodes[4];  // node records visited (wave-level), by class: skip, group, leaf
-#ifdef RT_TIMING_NODES  /* one atomic per node visit: counts are right, timings are not */
-#define RT_NODE_VISIT(k) if ((threadIdx.x & 63) == 0) atomicAdd(&g_rt_nodes[k], 1ull)
-#else
-#define RT_NODE_VISIT(k)
-#endif
-extern "C" int rt_debug_nodes(unsigned long long *out) {
-    unsigned long long zero[4] = {0};
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rt_nodes), sizeof zero);
-    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_rt_nodes), zero, sizeof zero);
-    return e == hipSuccess ? 0 : -4;
-}
+__shared__ unsigned rt_wave_nodes[4];  // node records this wave visited: skip, group, leaf (one wave per workgroup)
+#define RT_NODE_VISIT(k) if ((threadIdx.x & 63) == 0) atomicAdd(&rt_wave_nodes[k], 1u)
 #else
 #define RT_TIC(var)
 #define RT_NODE_VISIT(k)
@@ -709,6 +699,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
     long long tm_trace = 0, tm_shade = 0, tm_iters = 0, tm_lanes = 0;
     const long long tm_begin = clock64();
     const long long tm_rbegin = wall_clock64();
+    if (threadIdx.x < 4) rt_wave_nodes[threadIdx.x] = 0;
 #endif
     while (__ballot(mode != MODE_IDLE) != 0ull) {
         RT_TIC(tm0);
@@ -858,6 +849,8 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
             g_rt_timing[wv][1] = (unsigned long long)tm_rbegin;
             g_rt_timing[wv][2] = (unsigned long long)tm_iters | ((unsigned long long)tm_lanes << 32);
             g_rt_timing[wv][3] = (unsigned long long)(clock64() - tm_begin) | ((unsigned long long)(wall_clock64() - tm_rbegin) << 40);
+            g_rt_timing[wv][4] = (unsigned long long)rt_wave_nodes[0] | ((unsigned long long)rt_wave_nodes[1] << 32);
+            g_rt_timing[wv][5] = (unsigned long long)rt_wave_nodes[2];
         }
     }
 #endif
