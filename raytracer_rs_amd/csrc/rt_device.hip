@@ -633,7 +633,7 @@ __device__ __forceinline__ void ray_for_pixel(const RtCameraDev &cam, unsigned p
     dir = div_by_magnitude(v, magnitude(v));
 }
 
-enum { MODE_IDLE = 0, MODE_RADIANCE = 1, MODE_SHADOW = 2 };
+enum { MODE_IDLE = 0, MODE_RADIANCE = 1, MODE_SHADOW = 2, MODE_PAUSE = 3 };
 
 // World::color_at (rendering/world.rs:113-126) for one ray per lane.  Returns the colour in `acc`.
 //
@@ -703,7 +703,12 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
 #endif
     while (__ballot(mode != MODE_IDLE) != 0ull) {
         RT_TIC(tm0);
-        Best best = trace<NEST, STATS>(S, ro, rd, mode != MODE_IDLE, mode == MODE_SHADOW ? h_dist : (double)INFINITY, ctr);
+        const bool tracing = mode == MODE_RADIANCE || mode == MODE_SHADOW;
+        Best best;
+        best.t = __builtin_nan("");
+        best.leaf = -1;
+        if (__ballot(tracing) != 0ull)
+            best = trace<NEST, STATS>(S, ro, rd, tracing, mode == MODE_SHADOW ? h_dist : (double)INFINITY, ctr);
         RT_TIC(tm1);
         bool need_next = false;
         if (mode == MODE_SHADOW) {
@@ -799,9 +804,17 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
                 rd = div_by_magnitude(v, distance);
                 mode = MODE_SHADOW;
                 ctr.add(C_SHADOW);
+            } else if (nx_rem >= 0) {
+                // Miss (world.rs:124), or no light source (world.rs:86-89): black.  The lane's next ray waits one
+                // traversal: lanes that hit are tracing their shadow ray meanwhile, and a lane that went straight
+                // on would from then on shade while they trace and trace while they shade -- the wave would run
+                // the shading code every iteration instead of every other one.
+                mode = MODE_PAUSE;
             } else {
-                need_next = true;  // miss (world.rs:124), or no light source (world.rs:86-89): black
+                need_next = true;
             }
+        } else if (mode == MODE_PAUSE) {
+            need_next = true;
         }
         if (need_next) {
             if (nx_rem >= 0) {
