@@ -477,7 +477,13 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
                 if (any) ctr.add(C_PRIM_HITS + kind);
             }
         } else {
-            ni = skip;  // a group at the deepest level the scene declares: it has no children
+            // A group at the deepest level the scene declares has no children; the reference still transforms the
+            // ray and tests the (empty, always passing) bounds before it finds that out (world.rs:53-58).
+            if (STATS && active) {
+                ctr.add(C_XFORM);
+                ctr.add(C_AABB);
+            }
+            ni = skip;
         }
         if constexpr (NEST > 0) {
             if (ni != guess) nraw = node_fetch<WIDE>(S.nodes + ni);  // guessed wrong: fetch the record wanted

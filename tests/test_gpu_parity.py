@@ -444,6 +444,46 @@ def test_cone_linear_shortcut_survives_range_skipping(gpu, rt, orc):
     _lone_rays_agree(orc, w.scene(), ow, rays)
 
 
+def test_degenerate_worlds(gpu, rt, orc):
+    """Empty world, a childless group, no light source, and a flat list long enough to get range-skip nodes."""
+    cam, ocam = rt.Camera(40, 30, 1.0), orc.camera(40, 30, 1.0)
+
+    def both(w, ow):
+        ow.finalize()
+        img, st = w.scene().render(cam, stats=True)
+        plain, _ = w.scene().render(cam)
+        oc = orc.Counters()
+        ref = orc.render(ocam, ow, counters=oc)
+        assert np.array_equal(plain, img)
+        assert_frames_match(orc, img, ref)
+        counters_equal(st, oc)
+        return img
+
+    w, ow = rt.World(), orc.World()
+    w.light_source = rt.PointLight((-10, 10, -10), (1, 1, 1))
+    ow.set_light((-10, 10, -10), (1, 1, 1))
+    assert not both(w, ow).any()
+    w, ow = rt.World(), orc.World()
+    w.light_source = rt.PointLight((-10, 10, -10), (1, 1, 1))
+    ow.set_light((-10, 10, -10), (1, 1, 1))
+    w.objects = [rt.Object.group(), rt.Object.sphere(transformation=rt.Matrix4.translate(0, 0, -5))]
+    ow.add(orc.GROUP, orc.identity())
+    ow.add(orc.SPHERE, orc.translate(0, 0, -5))
+    assert both(w, ow).any()
+    w, ow = rt.World(), orc.World()  # world.rs:86-89: no light, everything black, but the camera rays are still cast
+    w.objects = [rt.Object.sphere(transformation=rt.Matrix4.translate(0, 0, -5))]
+    ow.add(orc.SPHERE, orc.translate(0, 0, -5))
+    assert not both(w, ow).any()
+    w, ow = rt.World(), orc.World()
+    w.light_source = rt.PointLight((-10, 10, -10), (1, 1, 1))
+    ow.set_light((-10, 10, -10), (1, 1, 1))
+    for i in range(40):
+        x, y = float(i % 10) - 4.5, float(i // 10) - 1.5
+        w.objects.append(rt.Object.sphere(transformation=rt.Matrix4.translate(x, y, -6.0) * rt.Matrix4.scale(0.4, 0.4, 0.4)))
+        ow.add(orc.SPHERE, orc.mul(orc.translate(x, y, -6.0), orc.scale(0.4, 0.4, 0.4)))
+    assert both(w, ow).any()
+
+
 # --------------------------------------------------------------------------- rows, bands, sizes, depth
 def test_row_ranges_and_bands_tile_the_frame(gpu, rt, orc):
     cam, world, ocam, oworld = load_both(rt, orc, "chapter_11", 203, 77)
