@@ -639,8 +639,6 @@ __device__ __forceinline__ void ray_for_pixel(const RtCameraDev &cam, unsigned p
     dir = div_by_magnitude(v, magnitude(v));
 }
 
-enum { MODE_IDLE = 0, MODE_RADIANCE = 1, MODE_SHADOW = 2, MODE_PAUSE = 3 };
-
 // World::color_at (rendering/world.rs:113-126) for one ray per lane.  Returns the colour in `acc`.
 //
 // The reference's recursion  color = surface + reflected*k_r + refracted*k_t  (world.rs:101-110, with
@@ -648,20 +646,19 @@ enum { MODE_IDLE = 0, MODE_RADIANCE = 1, MODE_SHADOW = 2, MODE_PAUSE = 3 };
 // sum over the nodes of the ray tree of  weight(node) * surface(node), weight being the product of the factors on
 // the path from the root.  That differs from the nested form only by floating-point reassociation (a few ulp).
 //
-// Per hit, everything is computed at once -- the surface colour for both outcomes of the shadow test, and the
-// reflection and refraction rays, which go onto a per-lane stack (refraction first, so the reflection subtree is
-// walked first) -- and then the shadow ray is traced.  While it is in flight a lane keeps only the two candidate
-// sums and the distance to the light; when it returns the lane picks one and pops its next ray.
+// One round of the loop takes every lane's current radiance ray through: traversal; for the lanes that hit, shading
+// for both outcomes of the shadow test and the reflection and refraction rays (pushed on a per-lane stack, refraction
+// first, so that the reflection subtree is walked first); traversal of the shadow rays; choice between the two sums;
+// next ray from the stack.  All lanes of a wave are thus always in the same phase: the two traversals never mix
+// scattered radiance rays with the coherent shadow rays, and the shading code runs once per round.  A lane whose
+// ray missed simply sits out the shadow traversal.
 template <int NEST, bool STATS>
 __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 rd, int remaining0, V3 &acc,
                                          Ctr<STATS> &ctr) {
-    int mode = valid ? MODE_RADIANCE : MODE_IDLE;
+    bool have = valid;  // (ro, rd, w, remaining) is a radiance ray to trace
     double w = 1.0;
     int remaining = remaining0;
-    acc = mk(0.0, 0.0, 0.0);   // while a shadow ray is in flight: the sum if the hit is in shadow
-    V3 acc_lit = acc;          // ... and the sum if it is not
-    double h_dist = 0.0;
-    int h_flags = 0;
+    acc = mk(0.0, 0.0, 0.0);
 
     // Pending rays (origin, direction, weight, remaining budget), last in first out.  The newest one lives in
     // registers (nx_*, valid while nx_rem >= 0); below it, the first LDS_LEVELS entries live in the workgroup's LDS
@@ -707,156 +704,141 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
     const long long tm_rbegin = wall_clock64();
     if (threadIdx.x < 4) rt_wave_nodes[threadIdx.x] = 0;
 #endif
-    while (__ballot(mode != MODE_IDLE) != 0ull) {
+    while (__ballot(have) != 0ull) {
         RT_TIC(tm0);
-        const bool tracing = mode == MODE_RADIANCE || mode == MODE_SHADOW;
-        Best best;
-        best.t = __builtin_nan("");
-        best.leaf = -1;
-        if (__ballot(tracing) != 0ull)
-            best = trace<NEST, STATS>(S, ro, rd, tracing, mode == MODE_SHADOW ? h_dist : (double)INFINITY, ctr);
+        const Best best = trace<NEST, STATS>(S, ro, rd, have, (double)INFINITY, ctr);
         RT_TIC(tm1);
-        bool need_next = false;
-        if (mode == MODE_SHADOW) {
-            const bool in_shadow = best.leaf >= 0 && best.t < h_dist;  // world.rs:145-148
-            if (!in_shadow) {
+        const bool shade = have && best.leaf >= 0 && S.light.has_light;  // else black: world.rs:124, world.rs:86-89
+        V3 acc_lit = acc;         // the sum if the hit is not in shadow (acc: if it is)
+        V3 sro = ro, srd = rd;    // the shadow ray
+        double h_dist = 0.0;
+        int h_flags = 0;
+        if (shade) {
+            // Intersection::prepare_computations (rendering/intersections.rs:45-63)
+            const RtSurface *s = S.surfaces + best.leaf;
+            V3 point = ro + rd * best.t;
+            V3 object_point;
+            V3 normal = normal_at(s, point, object_point);
+            V3 eye = -rd;
+            if (dot(normal, eye) < 0.0) normal = -normal;
+            V3 over = point + normal * EPS;
+            ctr.add(C_SHADES);
+
+            V3 shadowed, lit;
+            lighting<STATS>(s, S.light, point, object_point, eye, normal, shadowed, lit, h_flags, ctr);
+            acc_lit = acc + lit * w;
+            acc = acc + shadowed * w;
+
+            const double reflectivity = s->reflectivity;
+            const double transparency = s->transparency;
+            bool do_reflect = remaining != 0 && reflectivity != 0.0;   // world.rs:156-162
+            bool do_refract = remaining != 0 && transparency != 0.0;   // world.rs:175-181
+            double cos_i = dot(eye, normal);
+            // n1/n2 as Intersection::prepare_computations leaves them when handed the one-element list [self]
+            // (intersections.rs:41-43,66-103): n1 = 1.0, n2 = the hit object's refractive index; a non-finite t
+            // fails float_equal(t, t) and leaves both at 1.0.
+            const double n1 = 1.0;
+            const double n2 = (fabs(best.t - best.t) < EPS) ? s->refractive_index : 1.0;
+            V3 refr_dir = mk(0.0, 0.0, 0.0);
+            if (do_refract) {  // world.rs:183-194
+                ctr.add(C_REFRACT_SETUPS);
+                double n_ratio = n1 / n2;
+                double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+                if (sin2_t > 1.0) {
+                    do_refract = false;
+                } else {
+                    double cos_t = sqrt(1.0 - sin2_t);
+                    refr_dir = normal * (n_ratio * cos_i - cos_t) - eye * n_ratio;
+                }
+            }
+            double w_reflect = w * reflectivity;
+            double w_refract = w * transparency;
+            if (reflectivity > 0.0 && transparency > 0.0) {  // world.rs:105-108, intersections.rs:123-136
+                ctr.add(C_SCHLICK);
+                double c = cos_i;
+                double reflectance;
+                bool total = false;
+                if (n1 > n2) {
+                    double n = n1 / n2;
+                    double sin2_t = (n * n) * (1.0 - c * c);
+                    if (sin2_t > 1.0) total = true;
+                    c = sqrt(1.0 - sin2_t);
+                }
+                if (total) {
+                    reflectance = 1.0;
+                } else {
+                    double q = (n1 - n2) / (n1 + n2);
+                    double r0 = q * q;
+                    double m = 1.0 - c;
+                    double m2 = m * m;
+                    double m5 = m * (m2 * m2);  // powi(5)
+                    reflectance = r0 + (1.0 - r0) * m5;
+                }
+                w_reflect = w_reflect * reflectance;
+                w_refract = w_refract * (1.0 - reflectance);
+            }
+            const int child_remaining = remaining - 1;
+            if (do_refract) {  // under_point, direction (intersections.rs:63, world.rs:194)
+                ctr.add(C_REFRACT);
+                push(point - normal * EPS, refr_dir, w_refract, child_remaining);
+            }
+            if (do_reflect) {  // over_point, reflect_vector (intersections.rs:60-62)
+                ctr.add(C_REFLECT);
+                push(over, reflect(rd, normal), w_reflect, child_remaining);
+            }
+
+            // World::is_shadowed (rendering/world.rs:128-141)
+            V3 v = light_pos - over;
+            h_dist = magnitude(v);
+            sro = over;
+            srd = div_by_magnitude(v, h_dist);
+            ctr.add(C_SHADOW);
+        }
+        RT_TIC(tm2);
+        if (__ballot(shade) != 0ull) {
+            const Best occluder = trace<NEST, STATS>(S, sro, srd, shade, h_dist, ctr);
+            const bool in_shadow = occluder.leaf >= 0 && occluder.t < h_dist;  // world.rs:145-148
+            if (shade && !in_shadow) {
                 acc = acc_lit;
                 if (STATS) {
                     if (h_flags & 1) ctr.add(C_LIT);
                     if (h_flags & 2) ctr.add(C_SPECULAR);
                 }
             }
-            need_next = true;
-        } else if (mode == MODE_RADIANCE) {
-            if (best.leaf >= 0 && S.light.has_light) {
-                // Intersection::prepare_computations (rendering/intersections.rs:45-63)
-                const RtSurface *s = S.surfaces + best.leaf;
-                V3 point = ro + rd * best.t;
-                V3 object_point;
-                V3 normal = normal_at(s, point, object_point);
-                V3 eye = -rd;
-                if (dot(normal, eye) < 0.0) normal = -normal;
-                V3 over = point + normal * EPS;
-                ctr.add(C_SHADES);
-
-                V3 shadowed, lit;
-                lighting<STATS>(s, S.light, point, object_point, eye, normal, shadowed, lit, h_flags, ctr);
-                acc_lit = acc + lit * w;
-                acc = acc + shadowed * w;
-
-                const double reflectivity = s->reflectivity;
-                const double transparency = s->transparency;
-                bool do_reflect = remaining != 0 && reflectivity != 0.0;   // world.rs:156-162
-                bool do_refract = remaining != 0 && transparency != 0.0;   // world.rs:175-181
-                double cos_i = dot(eye, normal);
-                // n1/n2 as Intersection::prepare_computations leaves them when handed the one-element list [self]
-                // (intersections.rs:41-43,66-103): n1 = 1.0, n2 = the hit object's refractive index; a non-finite t
-                // fails float_equal(t, t) and leaves both at 1.0.
-                const double n1 = 1.0;
-                const double n2 = (fabs(best.t - best.t) < EPS) ? s->refractive_index : 1.0;
-                V3 refr_dir = mk(0.0, 0.0, 0.0);
-                if (do_refract) {  // world.rs:183-194
-                    ctr.add(C_REFRACT_SETUPS);
-                    double n_ratio = n1 / n2;
-                    double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
-                    if (sin2_t > 1.0) {
-                        do_refract = false;
-                    } else {
-                        double cos_t = sqrt(1.0 - sin2_t);
-                        refr_dir = normal * (n_ratio * cos_i - cos_t) - eye * n_ratio;
-                    }
-                }
-                double w_reflect = w * reflectivity;
-                double w_refract = w * transparency;
-                if (reflectivity > 0.0 && transparency > 0.0) {  // world.rs:105-108, intersections.rs:123-136
-                    ctr.add(C_SCHLICK);
-                    double c = cos_i;
-                    double reflectance;
-                    bool total = false;
-                    if (n1 > n2) {
-                        double n = n1 / n2;
-                        double sin2_t = (n * n) * (1.0 - c * c);
-                        if (sin2_t > 1.0) total = true;
-                        c = sqrt(1.0 - sin2_t);
-                    }
-                    if (total) {
-                        reflectance = 1.0;
-                    } else {
-                        double q = (n1 - n2) / (n1 + n2);
-                        double r0 = q * q;
-                        double m = 1.0 - c;
-                        double m2 = m * m;
-                        double m5 = m * (m2 * m2);  // powi(5)
-                        reflectance = r0 + (1.0 - r0) * m5;
-                    }
-                    w_reflect = w_reflect * reflectance;
-                    w_refract = w_refract * (1.0 - reflectance);
-                }
-                const int child_remaining = remaining - 1;
-                if (do_refract) {  // under_point, direction (intersections.rs:63, world.rs:194)
-                    ctr.add(C_REFRACT);
-                    push(point - normal * EPS, refr_dir, w_refract, child_remaining);
-                }
-                if (do_reflect) {  // over_point, reflect_vector (intersections.rs:60-62)
-                    ctr.add(C_REFLECT);
-                    push(over, reflect(rd, normal), w_reflect, child_remaining);
-                }
-
-                // World::is_shadowed (rendering/world.rs:128-141)
-                V3 v = light_pos - over;
-                double distance = magnitude(v);
-                h_dist = distance;
-                ro = over;
-                rd = div_by_magnitude(v, distance);
-                mode = MODE_SHADOW;
-                ctr.add(C_SHADOW);
-            } else if (nx_rem >= 0) {
-                // Miss (world.rs:124), or no light source (world.rs:86-89): black.  The lane's next ray waits one
-                // traversal: lanes that hit are tracing their shadow ray meanwhile, and a lane that went straight
-                // on would from then on shade while they trace and trace while they shade -- the wave would run
-                // the shading code every iteration instead of every other one.
-                mode = MODE_PAUSE;
-            } else {
-                need_next = true;
-            }
-        } else if (mode == MODE_PAUSE) {
-            need_next = true;
         }
-        if (need_next) {
-            if (nx_rem >= 0) {
-                ro = nx_o;
-                rd = nx_d;
-                w = nx_w;
-                remaining = nx_rem;
-                mode = MODE_RADIANCE;
-                nx_rem = -1;
-                if (sp > 0) {
-                    sp--;
-                    if (sp < LDS_LEVELS) {
-                        const double *e = lds + sp * (8 * 64);
-                        nx_o = mk(e[0 * 64], e[1 * 64], e[2 * 64]);
-                        nx_d = mk(e[3 * 64], e[4 * 64], e[5 * 64]);
-                        nx_w = e[6 * 64];
-                        nx_rem = __double2loint(e[7 * 64]);
-                    } else {
-                        const int d = sp - LDS_LEVELS;
-                        nx_o = mk(stk[d][0], stk[d][1], stk[d][2]);
-                        nx_d = mk(stk[d][3], stk[d][4], stk[d][5]);
-                        nx_w = stk[d][6];
-                        nx_rem = stk_rem[d];
-                    }
+        RT_TIC(tm3);
+        // the lane's next ray
+        have = nx_rem >= 0;
+        if (have) {
+            ro = nx_o;
+            rd = nx_d;
+            w = nx_w;
+            remaining = nx_rem;
+            nx_rem = -1;
+            if (sp > 0) {
+                sp--;
+                if (sp < LDS_LEVELS) {
+                    const double *e = lds + sp * (8 * 64);
+                    nx_o = mk(e[0 * 64], e[1 * 64], e[2 * 64]);
+                    nx_d = mk(e[3 * 64], e[4 * 64], e[5 * 64]);
+                    nx_w = e[6 * 64];
+                    nx_rem = __double2loint(e[7 * 64]);
+                } else {
+                    const int d = sp - LDS_LEVELS;
+                    nx_o = mk(stk[d][0], stk[d][1], stk[d][2]);
+                    nx_d = mk(stk[d][3], stk[d][4], stk[d][5]);
+                    nx_w = stk[d][6];
+                    nx_rem = stk_rem[d];
                 }
-            } else {
-                mode = MODE_IDLE;
             }
         }
 #ifdef RT_TIMING
         {
-            const long long tm2 = clock64();
-            tm_trace += tm1 - tm0;
-            tm_shade += tm2 - tm1;
+            const long long tm4 = clock64();
+            tm_trace += (tm1 - tm0) + (tm3 - tm2);
+            tm_shade += (tm2 - tm1) + (tm4 - tm3);
             tm_iters += 1;
-            tm_lanes += __popcll(__ballot(mode != MODE_IDLE));
+            tm_lanes += __popcll(__ballot(have));
         }
 #endif
     }
