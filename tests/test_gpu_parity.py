@@ -588,3 +588,47 @@ def test_full_4k_frame(gpu, rt, orc):
     for r in range(8):
         scene.render(cam, bands=(16, r, 8), out=acc)
     assert np.array_equal(acc, img)
+
+
+def _full_size_checks(orc, scene, cam, ocam, oworld, n_sample_bands, band_rows=4):
+    """What can be checked on a frame too large for the oracle to render whole: row bands spread over the frame
+    against the oracle (colours and, for the same rows, every counter); the counting and the plain kernel agree on
+    all of it; the ray count adds up; 16-row bands dealt to 8 ranks reassemble the frame."""
+    h, w = cam.vsize, cam.hsize
+    img, st = scene.render(cam, stats=True)
+    plain, _ = scene.render(cam)
+    assert np.array_equal(plain, img), "counting and plain kernels disagree"
+    assert st.primary == w * h and st.rays == st.primary + st.shadow + st.reflect + st.refract
+    for k in range(n_sample_bands):
+        y0 = ((h - band_rows) * k // (n_sample_bands - 1)) // band_rows * band_rows
+        oc = orc.Counters()
+        ref = orc.render(ocam, oworld, threads=16, rows=(y0, y0 + band_rows), counters=oc)
+        assert_frames_match(orc, img[y0:y0 + band_rows], ref[y0:y0 + band_rows])
+        del ref
+        _, pst = scene.render(cam, rows=(y0, y0 + band_rows), stats=True, out=plain)  # rows of the whole-frame buffer
+        counters_equal(pst, oc)
+        assert np.array_equal(plain[y0:y0 + band_rows], img[y0:y0 + band_rows])
+    plain.fill(0.0)
+    for r in range(8):
+        scene.render(cam, bands=(16, r, 8), out=plain)
+    assert np.array_equal(plain, img)
+
+
+def test_full_4k_hexagon_groups(gpu, rt, orc):
+    """chapter_14 (327 leaves under 17 groups) at 3840x2160."""
+    cam, world, ocam, oworld = load_both(rt, orc, "chapter_14", 3840, 2160)
+    _full_size_checks(orc, world.scene(), cam, ocam, oworld, n_sample_bands=12)
+
+
+def test_full_8k_generated_hierarchy(gpu, rt, orc):
+    """The 10 001-leaf, three-level hierarchy at 7680x4320."""
+    import tomli
+
+    from raytracer_rs_amd import synthetic
+
+    text = synthetic.large_scene()
+    sf = rt.SceneFile.from_str(text)
+    cam, world = sf.build_camera(), sf.build_world()
+    assert (cam.hsize, cam.vsize) == (7680, 4320)
+    ocam, oworld = orc.scene_from_dict(tomli.loads(text))
+    _full_size_checks(orc, world.scene(), cam, ocam, oworld, n_sample_bands=8)
