@@ -207,7 +207,10 @@ __device__ __forceinline__ bool hit_sphere(V3 o, V3 d, bool on, int leaf, Best &
     if (disc < 0.0) return false;
     double sq = sqrt(disc);
     double den = 2.0 * a;
-    cand_ordered(on, (-b - sq) / den, on, (-b + sq) / den, leaf, best);
+    // The far root can only be the closest hit when the near one is negative (or NaN): most rays never need it.
+    double t = (-b - sq) / den;
+    if (on && !(t >= 0.0)) t = (-b + sq) / den;
+    cand(on, t, leaf, best);
     return true;
 }
 
@@ -256,22 +259,31 @@ __device__ __forceinline__ bool hit_caps(V3 o, V3 d, double minimum, double maxi
 
 // The two wall roots of a cylinder or cone, each kept when its y lies strictly between the limits
 // (cylinders.rs:78-96, cones.rs:85-103)
+template <bool COUNT>  // COUNT: the caller wants to know whether the reference's hit list is empty, not only the closest hit
 __device__ __forceinline__ bool wall_roots(V3 o, V3 d, double b, double sq, double den, double minimum, double maximum,
                                            bool on, int leaf, Best &best) {
-    double t0 = (-b - sq) / den;
-    double t1 = (-b + sq) / den;
-    const bool swap = t0 > t1;
-    double ta = swap ? t1 : t0;
-    double tb = swap ? t0 : t1;
+    // The reference computes both roots and swaps them when t0 > t1.  sq >= 0, so -b - sq <= -b + sq, and a correctly
+    // rounded quotient is monotonic in its numerator: t0 <= t1 when den > 0 and t0 >= t1 when den < 0 (a cone's `a` can
+    // be negative).  The smaller root is therefore known before either division; with a NaN anywhere both roots are
+    // NaN and neither is accepted, whichever way round they are named.
+    const bool swap = !(den > 0.0);
+    double ta = (swap ? (-b + sq) : (-b - sq)) / den;
     double y0 = o.y + ta * d.y;
-    double y1 = o.y + tb * d.y;
     const bool in0 = minimum < y0 && y0 < maximum;
-    const bool in1 = minimum < y1 && y1 < maximum;
-    cand_ordered(in0 & on, ta, in1 & on, tb, leaf, best);
+    bool in1 = false;
+    if (COUNT || (on && !(in0 && ta >= 0.0))) {  // the larger root matters only when the smaller is no hit
+        double tb = (swap ? (-b - sq) : (-b + sq)) / den;
+        double y1 = o.y + tb * d.y;
+        in1 = minimum < y1 && y1 < maximum;
+        cand_ordered(in0 & on, ta, in1 & on, tb, leaf, best);
+    } else {
+        cand(in0 & on, ta, leaf, best);
+    }
     return in0 | in1;
 }
 
 // geometry/cylinders.rs:57-99
+template <bool COUNT>
 __device__ __forceinline__ bool hit_cylinder(V3 o, V3 d, double minimum, double maximum, bool closed, bool on,
                                              int leaf, Best &best) {
     double a = d.x * d.x + d.z * d.z;
@@ -281,13 +293,14 @@ __device__ __forceinline__ bool hit_cylinder(V3 o, V3 d, double minimum, double 
         double c = o.x * o.x + o.z * o.z - 1.0;
         double disc = b * b - 4.0 * a * c;
         if (disc < 0.0) return false;  // no cap test on this branch (cylinders.rs:73-75)
-        any = wall_roots(o, d, b, sqrt(disc), 2.0 * a, minimum, maximum, on, leaf, best);
+        any = wall_roots<COUNT>(o, d, b, sqrt(disc), 2.0 * a, minimum, maximum, on, leaf, best);
     }
     const bool caps = hit_caps<false>(o, d, minimum, maximum, closed, on, leaf, best);
     return any | caps;
 }
 
 // geometry/cones.rs:57-107
+template <bool COUNT>
 __device__ __forceinline__ bool hit_cone(V3 o, V3 d, double minimum, double maximum, bool closed, bool on, int leaf,
                                          Best &best) {
     double a = d.x * d.x - d.y * d.y + d.z * d.z;
@@ -304,7 +317,7 @@ __device__ __forceinline__ bool hit_cone(V3 o, V3 d, double minimum, double maxi
     } else {
         double disc = b * b - 4.0 * a * c;
         // a negative discriminant still falls through to the caps (cones.rs:80-83)
-        if (!(disc < 0.0)) any = wall_roots(o, d, b, sqrt(disc), 2.0 * a, minimum, maximum, on, leaf, best);
+        if (!(disc < 0.0)) any = wall_roots<COUNT>(o, d, b, sqrt(disc), 2.0 * a, minimum, maximum, on, leaf, best);
     }
     const bool caps = hit_caps<true>(o, d, minimum, maximum, closed, on, leaf, best);
     return any | caps;
@@ -468,8 +481,8 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
                 case RT_SPHERE: any = hit_sphere(lo, ld, on, leaf, best); break;
                 case RT_PLANE: any = hit_plane(lo, ld, on, leaf, best); break;
                 case RT_CUBE: any = hit_cube(lo, ld, on, leaf, best); break;
-                case RT_CYLINDER: any = hit_cylinder(lo, ld, a0, a1, (tag & RT_NODE_CLOSED) != 0, on, leaf, best); break;
-                default: any = hit_cone(lo, ld, a0, a1, (tag & RT_NODE_CLOSED) != 0, on, leaf, best); break;
+                case RT_CYLINDER: any = hit_cylinder<STATS>(lo, ld, a0, a1, (tag & RT_NODE_CLOSED) != 0, on, leaf, best); break;
+                default: any = hit_cone<STATS>(lo, ld, a0, a1, (tag & RT_NODE_CLOSED) != 0, on, leaf, best); break;
             }
             if (STATS && active) {
                 ctr.add(C_XFORM);
@@ -488,6 +501,9 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
         if constexpr (NEST > 0) {
             if (ni != guess) nraw = node_fetch<WIDE>(S.nodes + ni);  // guessed wrong: fetch the record wanted
         }
+        // One definition of the closest hit per iteration: without it the optimiser carries two copies of (t, leaf)
+        // round the loop -- the one the tests read and the one the caller gets -- and moves both at every join.
+        asm volatile("" : "+v"(best.t), "+v"(best.leaf));
         raw = nraw;
         i = uniform(ni);  // every operand above is wave-uniform; keep the index in an SGPR
     }
