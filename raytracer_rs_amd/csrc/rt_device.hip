@@ -168,6 +168,28 @@ __device__ __forceinline__ void cand_ordered(bool oka, double ta, bool okb, doub
     const bool first = oka & (ta >= 0.0);
     cand(first | okb, first ? ta : tb, leaf, b);
 }
+__device__ __forceinline__ double hit_limit(const Best &b, double far) { return fmin(b.t, far); }
+__device__ __forceinline__ bool settled(const Best &) { return false; }
+__device__ __forceinline__ void pin(Best &b) { asm volatile("" : "+v"(b.t), "+v"(b.leaf)); }
+
+// What World::is_shadowed (rendering/world.rs:128-149) asks of the same traversal: is the closest hit with t >= 0
+// nearer than `far`?  Which object it belongs to does not matter, and a lane that has its answer (any candidate
+// with 0 <= t < far settles it) needs no further range of nodes opened on its behalf.
+struct Occluded {
+    double t;  // closest so far, as in Best
+    double far;
+};
+__device__ __forceinline__ void cand(bool ok, double t, int, Occluded &b) {
+    const bool better = ok & (t >= 0.0) & !(t >= b.t);
+    b.t = better ? t : b.t;
+}
+__device__ __forceinline__ void cand_ordered(bool oka, double ta, bool okb, double tb, int leaf, Occluded &b) {
+    const bool first = oka & (ta >= 0.0);
+    cand(first | okb, first ? ta : tb, leaf, b);
+}
+__device__ __forceinline__ double hit_limit(const Occluded &b, double) { return b.far; }
+__device__ __forceinline__ bool settled(const Occluded &b) { return b.t < b.far; }
+__device__ __forceinline__ void pin(Occluded &b) { asm volatile("" : "+v"(b.t)); }
 
 // geometry/cubes.rs:41-59 (threshold EPSILON, extents -1..1) and geometry/bounds.rs:110-128 (threshold 1e-10)
 __device__ __forceinline__ void check_axis(double origin, double direction, double lo, double hi, double threshold,
@@ -199,7 +221,8 @@ __device__ __forceinline__ bool aabb_hit(const double (&bb)[6], V3 o, V3 d) {
 }
 
 // geometry/sphere.rs:51-74.  a = d.d >= 0, so (-b - sq)/(2a) <= (-b + sq)/(2a) unless one is NaN.
-__device__ __forceinline__ bool hit_sphere(V3 o, V3 d, bool on, int leaf, Best &best) {
+template <class B>
+__device__ __forceinline__ bool hit_sphere(V3 o, V3 d, bool on, int leaf, B &best) {
     double a = dot(d, d);
     double b = 2.0 * dot(d, o);
     double c = dot(o, o) - 1.0;
@@ -215,14 +238,16 @@ __device__ __forceinline__ bool hit_sphere(V3 o, V3 d, bool on, int leaf, Best &
 }
 
 // geometry/planes.rs:46-56
-__device__ __forceinline__ bool hit_plane(V3 o, V3 d, bool on, int leaf, Best &best) {
+template <class B>
+__device__ __forceinline__ bool hit_plane(V3 o, V3 d, bool on, int leaf, B &best) {
     if (fabs(d.y) < EPS) return false;
     cand(on, -o.y / d.y, leaf, best);
     return true;
 }
 
 // geometry/cubes.rs:63-86.  Both roots are emitted only when !(tmin > tmax).
-__device__ __forceinline__ bool hit_cube(V3 o, V3 d, bool on, int leaf, Best &best) {
+template <class B>
+__device__ __forceinline__ bool hit_cube(V3 o, V3 d, bool on, int leaf, B &best) {
     double tmin, tmax, ytmin, ytmax, ztmin, ztmax;
     check_axis(o.x, d.x, -1.0, 1.0, EPS, tmin, tmax);
     check_axis(o.y, d.y, -1.0, 1.0, EPS, ytmin, ytmax);
@@ -238,9 +263,9 @@ __device__ __forceinline__ bool hit_cube(V3 o, V3 d, bool on, int leaf, Best &be
 }
 
 // geometry/cylinders.rs:124-144 (radius 1) and geometry/cones.rs:140-161 (radius |y|)
-template <bool CONE>
+template <bool CONE, class B>
 __device__ __forceinline__ bool hit_caps(V3 o, V3 d, double minimum, double maximum, bool closed, bool on, int leaf,
-                                         Best &best) {
+                                         B &best) {
     if (!closed || fabs(d.y - 0.0) < EPS) return false;
     double t0 = (minimum - o.y) / d.y;
     double x0 = o.x + t0 * d.x;
@@ -259,9 +284,9 @@ __device__ __forceinline__ bool hit_caps(V3 o, V3 d, double minimum, double maxi
 
 // The two wall roots of a cylinder or cone, each kept when its y lies strictly between the limits
 // (cylinders.rs:78-96, cones.rs:85-103)
-template <bool COUNT>  // COUNT: the caller wants to know whether the reference's hit list is empty, not only the closest hit
+template <bool COUNT, class B>  // COUNT: the caller wants to know whether the reference's hit list is empty, not only the closest hit
 __device__ __forceinline__ bool wall_roots(V3 o, V3 d, double b, double sq, double den, double minimum, double maximum,
-                                           bool on, int leaf, Best &best) {
+                                           bool on, int leaf, B &best) {
     // The reference computes both roots and swaps them when t0 > t1.  sq >= 0, so -b - sq <= -b + sq, and a correctly
     // rounded quotient is monotonic in its numerator: t0 <= t1 when den > 0 and t0 >= t1 when den < 0 (a cone's `a` can
     // be negative).  The smaller root is therefore known before either division; with a NaN anywhere both roots are
@@ -283,9 +308,9 @@ __device__ __forceinline__ bool wall_roots(V3 o, V3 d, double b, double sq, doub
 }
 
 // geometry/cylinders.rs:57-99
-template <bool COUNT>
+template <bool COUNT, class B>
 __device__ __forceinline__ bool hit_cylinder(V3 o, V3 d, double minimum, double maximum, bool closed, bool on,
-                                             int leaf, Best &best) {
+                                             int leaf, B &best) {
     double a = d.x * d.x + d.z * d.z;
     bool any = false;
     if (!(fabs(a - 0.0) < EPS)) {
@@ -293,16 +318,16 @@ __device__ __forceinline__ bool hit_cylinder(V3 o, V3 d, double minimum, double 
         double c = o.x * o.x + o.z * o.z - 1.0;
         double disc = b * b - 4.0 * a * c;
         if (disc < 0.0) return false;  // no cap test on this branch (cylinders.rs:73-75)
-        any = wall_roots<COUNT>(o, d, b, sqrt(disc), 2.0 * a, minimum, maximum, on, leaf, best);
+        any = wall_roots<COUNT, B>(o, d, b, sqrt(disc), 2.0 * a, minimum, maximum, on, leaf, best);
     }
-    const bool caps = hit_caps<false>(o, d, minimum, maximum, closed, on, leaf, best);
+    const bool caps = hit_caps<false, B>(o, d, minimum, maximum, closed, on, leaf, best);
     return any | caps;
 }
 
 // geometry/cones.rs:57-107
-template <bool COUNT>
+template <bool COUNT, class B>
 __device__ __forceinline__ bool hit_cone(V3 o, V3 d, double minimum, double maximum, bool closed, bool on, int leaf,
-                                         Best &best) {
+                                         B &best) {
     double a = d.x * d.x - d.y * d.y + d.z * d.z;
     double b = 2.0 * o.x * d.x - 2.0 * o.y * d.y + 2.0 * o.z * d.z;
     double c = o.x * o.x - o.y * o.y + o.z * o.z;
@@ -317,9 +342,9 @@ __device__ __forceinline__ bool hit_cone(V3 o, V3 d, double minimum, double maxi
     } else {
         double disc = b * b - 4.0 * a * c;
         // a negative discriminant still falls through to the caps (cones.rs:80-83)
-        if (!(disc < 0.0)) any = wall_roots<COUNT>(o, d, b, sqrt(disc), 2.0 * a, minimum, maximum, on, leaf, best);
+        if (!(disc < 0.0)) any = wall_roots<COUNT, B>(o, d, b, sqrt(disc), 2.0 * a, minimum, maximum, on, leaf, best);
     }
-    const bool caps = hit_caps<true>(o, d, minimum, maximum, closed, on, leaf, best);
+    const bool caps = hit_caps<true, B>(o, d, minimum, maximum, closed, on, leaf, best);
     return any | caps;
 }
 
@@ -401,9 +426,9 @@ __device__ __forceinline__ bool box_may_hit(const double (&bb)[6], V3 o, V3 inv,
 // are wave-uniform.  `far`: hits beyond it do not matter to the caller (range-skip nodes use it; the t parameter is
 // the same in every space because directions are never renormalised).  Per node: take the ray into the node's space (this uses up the matrix), request the following
 // record into the registers the matrix occupied, then run the shape or bounds test while that request is in flight.
-template <int D, int NEST, bool STATS>
+template <int D, int NEST, bool STATS, class B>
 __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end, V3 o, V3 d, bool active, double far,
-                                            Best &best, Ctr<STATS> &ctr) {
+                                            B &best, Ctr<STATS> &ctr) {
     constexpr bool WIDE = NEST > 0;
     if (begin >= end) return;
     NodeRaw raw = node_fetch<WIDE>(S.nodes + begin);
@@ -455,7 +480,7 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
                     dmax = fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z));
                     have_inv = true;
                 }
-                const bool may = active && (shortcut || box_may_hit(bb, o, inv_d, dmax, fmin(best.t, far)));
+                const bool may = active && !settled(best) && (shortcut || box_may_hit(bb, o, inv_d, dmax, hit_limit(best, far)));
                 ctr.visits += may ? 1u : 0u;
                 if (__ballot(may) == 0ull) ni = skip;
             }
@@ -468,7 +493,7 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
                     ctr.add(C_AABB);
                 }
                 if constexpr (!STATS) ctr.visits += inside ? 4u : 0u;
-                if (__ballot(inside) != 0ull) trace_range<D + 1, NEST, STATS>(S, i + 1, skip, lo, ld, inside, far, best, ctr);
+                if (__ballot(inside) != 0ull) trace_range<D + 1, NEST, STATS, B>(S, i + 1, skip, lo, ld, inside, far, best, ctr);
                 ni = skip;
             }
         } else if (kind != RT_GROUP) {
@@ -481,8 +506,8 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
                 case RT_SPHERE: any = hit_sphere(lo, ld, on, leaf, best); break;
                 case RT_PLANE: any = hit_plane(lo, ld, on, leaf, best); break;
                 case RT_CUBE: any = hit_cube(lo, ld, on, leaf, best); break;
-                case RT_CYLINDER: any = hit_cylinder<STATS>(lo, ld, a0, a1, (tag & RT_NODE_CLOSED) != 0, on, leaf, best); break;
-                default: any = hit_cone<STATS>(lo, ld, a0, a1, (tag & RT_NODE_CLOSED) != 0, on, leaf, best); break;
+                case RT_CYLINDER: any = hit_cylinder<STATS, B>(lo, ld, a0, a1, (tag & RT_NODE_CLOSED) != 0, on, leaf, best); break;
+                default: any = hit_cone<STATS, B>(lo, ld, a0, a1, (tag & RT_NODE_CLOSED) != 0, on, leaf, best); break;
             }
             if (STATS && active) {
                 ctr.add(C_XFORM);
@@ -503,7 +528,7 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
         }
         // One definition of the closest hit per iteration: without it the optimiser carries two copies of (t, leaf)
         // round the loop -- the one the tests read and the one the caller gets -- and moves both at every join.
-        asm volatile("" : "+v"(best.t), "+v"(best.leaf));
+        pin(best);
         raw = nraw;
         i = uniform(ni);  // every operand above is wave-uniform; keep the index in an SGPR
     }
@@ -515,8 +540,19 @@ __device__ __forceinline__ Best trace(const SceneK &S, V3 o, V3 d, bool active, 
     best.t = __builtin_nan("");
     best.leaf = -1;
     if (STATS && active) ctr.add(C_RAYS);
-    trace_range<0, NEST, STATS>(S, 0, S.n_nodes, o, d, active, far, best, ctr);
+    trace_range<0, NEST, STATS, Best>(S, 0, S.n_nodes, o, d, active, far, best, ctr);
     return best;
+}
+
+// World::is_shadowed's question about the ray (o, d): a hit with 0 <= t < distance?
+template <int NEST, bool STATS>
+__device__ __forceinline__ bool occluded(const SceneK &S, V3 o, V3 d, bool active, double distance, Ctr<STATS> &ctr) {
+    Occluded oc;
+    oc.far = distance;
+    oc.t = __builtin_nan("");
+    if (STATS && active) ctr.add(C_RAYS);
+    trace_range<0, NEST, STATS, Occluded>(S, 0, S.n_nodes, o, d, active, distance, oc, ctr);
+    return oc.t < distance;
 }
 
 // Shape::local_normal_at of the leaf kinds
@@ -812,8 +848,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
         }
         RT_TIC(tm2);
         if (__ballot(shade) != 0ull) {
-            const Best occluder = trace<NEST, STATS>(S, sro, srd, shade, h_dist, ctr);
-            const bool in_shadow = occluder.leaf >= 0 && occluder.t < h_dist;  // world.rs:145-148
+            const bool in_shadow = occluded<NEST, STATS>(S, sro, srd, shade, h_dist, ctr);  // world.rs:145-148
             if (shade && !in_shadow) {
                 acc = acc_lit;
                 if (STATS) {
@@ -1038,8 +1073,8 @@ __global__ __launch_bounds__(256) void is_shadowed_kernel(DeviceScene scene, con
         distance = magnitude(v);
         rd = div_by_magnitude(v, distance);
     }
-    Best best = trace<RT_MAX_GROUP_NESTING, false>(S, ro, rd, valid && lit_world, distance, ctr);
-    if (valid) out[i] = (lit_world && best.leaf >= 0 && best.t < distance) ? 1 : 0;
+    const bool hit = occluded<RT_MAX_GROUP_NESTING, false>(S, ro, rd, valid && lit_world, distance, ctr);
+    if (valid) out[i] = (lit_world && hit) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void normal_at_kernel(DeviceScene scene, const int *__restrict__ leaf,
