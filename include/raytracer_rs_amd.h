@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 enum {
     RT_OK = 0,
@@ -40,7 +40,8 @@ enum {
     RT_ERR_IO = -5,             /* SceneFile::from_file Err: fs::read_to_string (scenes/loader.rs:191) */
     RT_ERR_PARSE = -6,          /* SceneFile::from_file Err: toml::from_str (scenes/loader.rs:192) */
     RT_ERR_UNSUPPORTED = -7,    /* e.g. groups nested deeper than RT_MAX_GROUP_NESTING */
-    RT_ERR_NO_DEVICE = -8
+    RT_ERR_NO_DEVICE = -8,
+    RT_ERR_CAPACITY = -9        /* an output list was too short; the counts say how long it has to be */
 };
 
 /* enum Object (rendering/objects.rs:34-41) */
@@ -130,6 +131,15 @@ typedef struct rt_scene_info {
     int32_t _pad;
 } rt_scene_info;
 
+/* struct Computations (rendering/intersections.rs:12-24); `object` is an index into rt_world_desc.objects. */
+typedef struct rt_computations {
+    double time;
+    int32_t object;
+    int32_t inside;
+    double point[3], eye_vector[3], normal_vector[3], reflect_vector[3], over_point[3], under_point[3];
+    double n1, n2;
+} rt_computations;
+
 typedef struct rt_scene rt_scene;           /* a World resident on one GPU */
 typedef struct rt_scene_file rt_scene_file; /* struct SceneFile (scenes/loader.rs:21-26) */
 
@@ -164,6 +174,28 @@ int rt_color_at(const rt_scene *scene, const double *rays, uint32_t n, int32_t r
 /* World::intersect + Intersection::hit (rendering/world.rs:27-36, rendering/intersections.rs:37-39) for n rays:
  * t[i] and the index (into rt_world_desc.objects) of the hit object, or -1 / NaN when nothing is hit. */
 int rt_intersect(const rt_scene *scene, const double *rays, uint32_t n, double *t, int32_t *object);
+/* World::intersect itself (rendering/world.rs:27-36) for n rays: the whole list of intersections of ray i, stably
+ * sorted by t (negative t's included), in t[i*capacity ..] / object[i*capacity ..]; count[i] entries.  When some
+ * ray has more than `capacity` intersections the call returns RT_ERR_CAPACITY with every count[i] set to the
+ * length that ray needs (lists of rays within capacity are still complete).  A list that contains a NaN t comes
+ * back in an unspecified order (the reference's comparator calls NaN equal to everything, world.rs:34). */
+int rt_intersect_all(const rt_scene *scene, const double *rays, uint32_t n, uint32_t capacity, uint32_t *count,
+                     double *t, int32_t *object);
+/* Intersection::prepare_computations_for_intersections (rendering/intersections.rs:45-118) for n hits: hit i is
+ * (t[i], object[i]) on rays[i] and its intersection list is xs_t / xs_object [xs_begin[i], xs_begin[i+1])
+ * (xs_begin has n+1 entries).  xs_begin = NULL gives every hit the one-element list [hit], which is
+ * Intersection::prepare_computations (intersections.rs:41-43), the form World::color_at uses (world.rs:121). */
+int rt_prepare_computations(const rt_scene *scene, const double *rays, const double *t, const int32_t *object,
+                            uint32_t n, const uint32_t *xs_begin, const double *xs_t, const int32_t *xs_object,
+                            rt_computations *out);
+/* World::shade_hit, World::reflected_color, World::refracted_color (rendering/world.rs:80-111, 151-168, 170-198)
+ * for n Computations, with the recursion budget `remaining` of their _internal forms (RT_DEFAULT_DEPTH for the
+ * public ones). */
+int rt_shade_hit(const rt_scene *scene, const rt_computations *comps, uint32_t n, int32_t remaining, double *colors);
+int rt_reflected_color(const rt_scene *scene, const rt_computations *comps, uint32_t n, int32_t remaining,
+                       double *colors);
+int rt_refracted_color(const rt_scene *scene, const rt_computations *comps, uint32_t n, int32_t remaining,
+                       double *colors);
 /* World::is_shadowed (rendering/world.rs:128-149) for n points (3 doubles each). */
 int rt_is_shadowed(const rt_scene *scene, const double *points, uint32_t n, uint8_t *shadowed);
 /* Object::normal_at (rendering/objects.rs:171-184) of object[i] at points[i]. */

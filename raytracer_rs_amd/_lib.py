@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")
 
 RT_OK = 0
 ERR_NAMES = {-1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NOT_INVERTIBLE", -3: "RT_ERR_MATERIAL", -4: "RT_ERR_HIP",
-             -5: "RT_ERR_IO", -6: "RT_ERR_PARSE", -7: "RT_ERR_UNSUPPORTED", -8: "RT_ERR_NO_DEVICE"}
+             -5: "RT_ERR_IO", -6: "RT_ERR_PARSE", -7: "RT_ERR_UNSUPPORTED", -8: "RT_ERR_NO_DEVICE", -9: "RT_ERR_CAPACITY"}
 SPHERE, PLANE, CUBE, CYLINDER, CONE, GROUP = range(6)
 PATTERN_NONE, PATTERN_STRIPE, PATTERN_GRADIENT, PATTERN_RING, PATTERN_CHECKERS = -1, 0, 1, 2, 3
 MAX_GROUP_NESTING = 3
@@ -76,6 +76,13 @@ class Stats(C.Structure):
         return d
 
 
+class Computations(C.Structure):
+    """struct Computations (rendering/intersections.rs:12-24); `object` indexes the world's depth-first object list."""
+    _fields_ = [("time", C.c_double), ("object", C.c_int32), ("inside", C.c_int32), ("point", C.c_double * 3),
+                ("eye_vector", C.c_double * 3), ("normal_vector", C.c_double * 3), ("reflect_vector", C.c_double * 3),
+                ("over_point", C.c_double * 3), ("under_point", C.c_double * 3), ("n1", C.c_double), ("n2", C.c_double)]
+
+
 class RenderOpts(C.Structure):
     _fields_ = [("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("max_depth", C.c_int32),
                 ("collect_stats", C.c_int32), ("stream", C.c_void_p), ("band_rows", C.c_uint32),
@@ -100,6 +107,13 @@ SIGNATURES = {
     "rt_render_device": (C.c_int, [C.c_void_p, _P(CameraDesc), _P(RenderOpts), C.c_void_p, _P(Stats)]),
     "rt_color_at": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_int32, _P(C.c_double), _P(Stats)]),
     "rt_intersect": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, _P(C.c_double), _P(C.c_int32)]),
+    "rt_intersect_all": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_uint32, _P(C.c_uint32), _P(C.c_double),
+                                   _P(C.c_int32)]),
+    "rt_prepare_computations": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_double), _P(C.c_int32), C.c_uint32,
+                                          _P(C.c_uint32), _P(C.c_double), _P(C.c_int32), _P(Computations)]),
+    "rt_shade_hit": (C.c_int, [C.c_void_p, _P(Computations), C.c_uint32, C.c_int32, _P(C.c_double)]),
+    "rt_reflected_color": (C.c_int, [C.c_void_p, _P(Computations), C.c_uint32, C.c_int32, _P(C.c_double)]),
+    "rt_refracted_color": (C.c_int, [C.c_void_p, _P(Computations), C.c_uint32, C.c_int32, _P(C.c_double)]),
     "rt_is_shadowed": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, _P(C.c_uint8)]),
     "rt_normal_at": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_double), C.c_uint32, _P(C.c_double)]),
     "rt_ray_for_pixel": (C.c_int, [_P(CameraDesc), _P(C.c_uint32), _P(C.c_uint32), C.c_uint32, _P(C.c_double), C.c_int]),

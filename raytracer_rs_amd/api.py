@@ -361,6 +361,62 @@ class Scene:
                                      t.ctypes.data_as(C.POINTER(C.c_double)), obj.ctypes.data_as(C.POINTER(C.c_int32))))
         return t, obj
 
+    def intersect_all(self, rays: np.ndarray, capacity: int = 16):
+        """rt_intersect_all: per ray the sorted list [(t, object), ...] of World::intersect.  A list longer than
+        `capacity` makes the call again with the capacity the library reports."""
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        n = rays.shape[0]
+        while True:
+            count = np.zeros(n, dtype=np.uint32)
+            t = np.zeros((n, capacity), dtype=np.float64)
+            obj = np.zeros((n, capacity), dtype=np.int32)
+            rc = L.lib().rt_intersect_all(self._h, rays.ctypes.data_as(C.POINTER(C.c_double)), n, capacity,
+                                          count.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                          t.ctypes.data_as(C.POINTER(C.c_double)),
+                                          obj.ctypes.data_as(C.POINTER(C.c_int32)))
+            if rc == -9:  # RT_ERR_CAPACITY
+                capacity = int(count.max())
+                continue
+            L.check(rc)
+            return [[(float(t[i, k]), int(obj[i, k])) for k in range(int(count[i]))] for i in range(n)]
+
+    def prepare_computations(self, rays: np.ndarray, t: Sequence[float], objects: Sequence[int],
+                             xs: Optional[Sequence[Sequence[Tuple[float, int]]]] = None):
+        """rt_prepare_computations -> ctypes array of Computations; xs[i] is hit i's intersection list or None."""
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        n = rays.shape[0]
+        tt = np.ascontiguousarray(t, dtype=np.float64).reshape(-1)
+        oo = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        out = (L.Computations * max(1, n))()
+        begin = xs_t = xs_o = None
+        if xs is not None:
+            lists = [list(x) if x is not None else [(float(tt[i]), int(oo[i]))] for i, x in enumerate(xs)]
+            begin = np.zeros(n + 1, dtype=np.uint32)
+            begin[1:] = np.cumsum([len(x) for x in lists])
+            xs_t = np.array([e[0] for x in lists for e in x] or [0.0], dtype=np.float64)
+            xs_o = np.array([e[1] for x in lists for e in x] or [0], dtype=np.int32)
+        L.check(L.lib().rt_prepare_computations(
+            self._h, rays.ctypes.data_as(C.POINTER(C.c_double)), tt.ctypes.data_as(C.POINTER(C.c_double)),
+            oo.ctypes.data_as(C.POINTER(C.c_int32)), n,
+            begin.ctypes.data_as(C.POINTER(C.c_uint32)) if begin is not None else None,
+            xs_t.ctypes.data_as(C.POINTER(C.c_double)) if xs_t is not None else None,
+            xs_o.ctypes.data_as(C.POINTER(C.c_int32)) if xs_o is not None else None, out))
+        return out
+
+    def _part(self, fn, comps, n: int, remaining: int) -> np.ndarray:
+        out = np.zeros((n, 3), dtype=np.float64)
+        L.check(fn(self._h, comps, n, remaining, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def shade_hit(self, comps, n: int, remaining: int = L.DEFAULT_DEPTH) -> np.ndarray:
+        return self._part(L.lib().rt_shade_hit, comps, n, remaining)
+
+    def reflected_color(self, comps, n: int, remaining: int = L.DEFAULT_DEPTH) -> np.ndarray:
+        return self._part(L.lib().rt_reflected_color, comps, n, remaining)
+
+    def refracted_color(self, comps, n: int, remaining: int = L.DEFAULT_DEPTH) -> np.ndarray:
+        return self._part(L.lib().rt_refracted_color, comps, n, remaining)
+
     def is_shadowed(self, points: np.ndarray) -> np.ndarray:
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
         out = np.zeros(pts.shape[0], dtype=np.uint8)
@@ -439,6 +495,32 @@ class World:
     def hit(self, ray: Ray) -> Optional[Tuple[float, int]]:
         t, obj = self.scene().intersect(np.array([list(ray.origin) + list(ray.direction)]))
         return None if obj[0] < 0 else (float(t[0]), int(obj[0]))
+
+    def intersect(self, ray: Ray) -> List[Tuple[float, int]]:
+        """World::intersect (world.rs:27-36): every intersection as (t, object index), sorted by t."""
+        return self.scene().intersect_all(np.array([list(ray.origin) + list(ray.direction)]))[0]
+
+    def prepare_computations(self, t: float, obj: int, ray: Ray,
+                             xs: Optional[Sequence[Tuple[float, int]]] = None) -> L.Computations:
+        """Intersection::prepare_computations / _for_intersections (intersections.rs:41-118) of the hit (t, obj)."""
+        r = np.array([list(ray.origin) + list(ray.direction)])
+        return self.scene().prepare_computations(r, [t], [obj], None if xs is None else [xs])[0]
+
+    def _one(self, fn, comps: L.Computations, remaining: int) -> Tuple[float, float, float]:
+        arr = (L.Computations * 1)(comps)
+        return tuple(float(v) for v in fn(arr, 1, remaining)[0])
+
+    def shade_hit(self, comps: L.Computations, remaining: int = L.DEFAULT_DEPTH) -> Tuple[float, float, float]:
+        """World::shade_hit (world.rs:80-111)"""
+        return self._one(self.scene().shade_hit, comps, remaining)
+
+    def reflected_color(self, comps: L.Computations, remaining: int = L.DEFAULT_DEPTH) -> Tuple[float, float, float]:
+        """World::reflected_color (world.rs:151-168)"""
+        return self._one(self.scene().reflected_color, comps, remaining)
+
+    def refracted_color(self, comps: L.Computations, remaining: int = L.DEFAULT_DEPTH) -> Tuple[float, float, float]:
+        """World::refracted_color (world.rs:170-198)"""
+        return self._one(self.scene().refracted_color, comps, remaining)
 
     def color_at(self, ray: Ray, remaining: int = L.DEFAULT_DEPTH) -> Tuple[float, float, float]:
         """World::color_at (world.rs:113-126)"""

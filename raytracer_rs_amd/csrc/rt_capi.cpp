@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cerrno>
+#include <cstddef>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -361,6 +362,153 @@ int rt_intersect(const rt_scene *scene, const double *rays, uint32_t n, double *
     HIP_TRY(hipMemcpy(t, d_t.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(object, d_obj.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return RT_OK;
+}
+
+int rt_intersect_all(const rt_scene *scene, const double *rays, uint32_t n, uint32_t capacity, uint32_t *count,
+                     double *t, int32_t *object) {
+    if (!scene || ((!rays || !count) && n) || ((!t || !object) && n && capacity))
+        return set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!n) return RT_OK;
+    DeviceGuard guard(scene->device);
+    if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+    const size_t total = (size_t)n * capacity;
+    DeviceBuffer<double> d_rays, d_t;
+    DeviceBuffer<int32_t> d_obj;
+    DeviceBuffer<uint32_t> d_count;
+    HIP_TRY(d_rays.alloc((size_t)n * 6));
+    HIP_TRY(d_t.alloc(total));
+    HIP_TRY(d_obj.alloc(total));
+    HIP_TRY(d_count.alloc(n));
+    HIP_TRY(hipMemcpy(d_rays.p, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(rt::launch_intersect_all(scene->dev, d_rays.p, n, capacity, d_count.p, d_t.p, d_obj.p, nullptr));
+    HIP_TRY(hipMemcpy(count, d_count.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (total) {
+        HIP_TRY(hipMemcpy(t, d_t.p, total * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(object, d_obj.p, total * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        if (count[i] > capacity)
+            return set_error(RT_ERR_CAPACITY, "ray " + std::to_string(i) + " has " + std::to_string(count[i]) +
+                                                  " intersections, capacity is " + std::to_string(capacity));
+    return RT_OK;
+}
+
+namespace {
+
+static_assert(sizeof(rt_computations) == sizeof(RtComps) && offsetof(rt_computations, n1) == offsetof(RtComps, n1) &&
+                  offsetof(rt_computations, point) == offsetof(RtComps, point),
+              "rt_computations and RtComps must have one layout");
+
+// The leaf a Computations record refers to, or -1 (groups have no surface: the reference panics in normal_at).
+int32_t leaf_of(const rt_scene *scene, int32_t object) {
+    if (object < 0 || (size_t)object >= scene->object_to_leaf.size()) return -1;
+    return scene->object_to_leaf[(size_t)object];
+}
+
+// n1 and n2 of the hit (t, object) within the list xs (rendering/intersections.rs:65-103): walk the list keeping the
+// objects the ray is inside of; n1 is the last container's index before the hit is applied, n2 the one after.
+void refractive_indices(const rt_scene *scene, double t, int32_t object, const double *xs_t, const int32_t *xs_object,
+                        uint32_t xs_n, double &n1, double &n2) {
+    std::vector<int32_t> containers;
+    auto last_index = [&]() {
+        if (containers.empty()) return 1.0;
+        const int32_t leaf = leaf_of(scene, containers.back());
+        return leaf >= 0 ? scene->flat.surfaces[(size_t)leaf].refractive_index : 1.0;
+    };
+    n1 = 1.0;
+    n2 = 1.0;
+    for (uint32_t k = 0; k < xs_n; ++k) {
+        const bool is_hit = xs_object[k] == object && std::fabs(xs_t[k] - t) < 1e-5;  // float_equal, core/floats.rs:4-6
+        if (is_hit) n1 = last_index();
+        bool found = false;
+        for (size_t c = 0; c < containers.size(); ++c)
+            if (containers[c] == xs_object[k]) {
+                containers.erase(containers.begin() + (std::ptrdiff_t)c);
+                found = true;
+                break;
+            }
+        if (!found) containers.push_back(xs_object[k]);
+        if (is_hit) {
+            n2 = last_index();
+            break;
+        }
+    }
+}
+
+int shade_part(const rt_scene *scene, int part, const rt_computations *comps, uint32_t n, int32_t remaining,
+               double *colors) {
+    if (!scene || ((!comps || !colors) && n)) return set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (remaining < 0 || remaining > RT_MAX_DEPTH)
+        return set_error(RT_ERR_INVALID_ARGUMENT, "remaining must be within 0.." + std::to_string(RT_MAX_DEPTH));
+    if (!n) return RT_OK;
+    std::vector<RtComps> dev(n);
+    std::memcpy(dev.data(), comps, (size_t)n * sizeof(RtComps));
+    for (uint32_t i = 0; i < n; ++i) {
+        const int32_t leaf = leaf_of(scene, comps[i].object);
+        if (leaf < 0) return set_error(RT_ERR_INVALID_ARGUMENT, "Computations.object must be a leaf object of the world");
+        dev[i].object = leaf;
+    }
+    DeviceGuard guard(scene->device);
+    if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+    DeviceBuffer<RtComps> d_comps;
+    DeviceBuffer<double> d_colors;
+    HIP_TRY(d_comps.alloc(n));
+    HIP_TRY(d_colors.alloc((size_t)n * 3));
+    HIP_TRY(hipMemcpy(d_comps.p, dev.data(), (size_t)n * sizeof(RtComps), hipMemcpyHostToDevice));
+    HIP_TRY(rt::launch_shade_part(scene->dev, part, d_comps.p, n, remaining, d_colors.p, nullptr));
+    HIP_TRY(hipMemcpy(colors, d_colors.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+}  // namespace
+
+int rt_prepare_computations(const rt_scene *scene, const double *rays, const double *t, const int32_t *object,
+                            uint32_t n, const uint32_t *xs_begin, const double *xs_t, const int32_t *xs_object,
+                            rt_computations *out) {
+    if (!scene || ((!rays || !t || !object || !out) && n)) return set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (xs_begin && (!xs_t || !xs_object) && n && xs_begin[n] > xs_begin[0])
+        return set_error(RT_ERR_INVALID_ARGUMENT, "xs_begin given without xs_t / xs_object");
+    if (!n) return RT_OK;
+    std::vector<RtComps> dev(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const int32_t leaf = leaf_of(scene, object[i]);
+        if (leaf < 0)
+            return set_error(RT_ERR_INVALID_ARGUMENT, "Groups do not have a normal - normal_at should be called on child objects");
+        RtComps &c = dev[i];
+        std::memset(&c, 0, sizeof c);
+        c.time = t[i];
+        c.object = leaf;
+        if (xs_begin) {
+            if (xs_begin[i + 1] < xs_begin[i]) return set_error(RT_ERR_INVALID_ARGUMENT, "xs_begin must not decrease");
+            refractive_indices(scene, t[i], object[i], xs_t + xs_begin[i], xs_object + xs_begin[i], xs_begin[i + 1] - xs_begin[i], c.n1, c.n2);
+        } else {
+            refractive_indices(scene, t[i], object[i], t + i, object + i, 1, c.n1, c.n2);
+        }
+    }
+    DeviceGuard guard(scene->device);
+    if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+    DeviceBuffer<double> d_rays;
+    DeviceBuffer<RtComps> d_comps;
+    HIP_TRY(d_rays.alloc((size_t)n * 6));
+    HIP_TRY(d_comps.alloc(n));
+    HIP_TRY(hipMemcpy(d_rays.p, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_comps.p, dev.data(), (size_t)n * sizeof(RtComps), hipMemcpyHostToDevice));
+    HIP_TRY(rt::launch_prepare_computations(scene->dev, d_rays.p, n, d_comps.p, nullptr));
+    HIP_TRY(hipMemcpy(out, d_comps.p, (size_t)n * sizeof(RtComps), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) out[i].object = object[i];
+    return RT_OK;
+}
+
+int rt_shade_hit(const rt_scene *scene, const rt_computations *comps, uint32_t n, int32_t remaining, double *colors) {
+    return shade_part(scene, RT_PART_SHADE_HIT, comps, n, remaining, colors);
+}
+int rt_reflected_color(const rt_scene *scene, const rt_computations *comps, uint32_t n, int32_t remaining,
+                       double *colors) {
+    return shade_part(scene, RT_PART_REFLECTED, comps, n, remaining, colors);
+}
+int rt_refracted_color(const rt_scene *scene, const rt_computations *comps, uint32_t n, int32_t remaining,
+                       double *colors) {
+    return shade_part(scene, RT_PART_REFRACTED, comps, n, remaining, colors);
 }
 
 int rt_is_shadowed(const rt_scene *scene, const double *points, uint32_t n, uint8_t *shadowed) {

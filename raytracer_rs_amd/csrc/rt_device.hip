@@ -154,6 +154,7 @@ struct SceneK {
 // and from then on t is an ordinary number and `!(x >= t)` is `x < t`.  Candidates arrive in the reference's emission
 // order, so the strict comparison keeps the earliest of equal t's.  Written with selects: no branch per candidate.
 struct Best {
+    static constexpr bool every = false;  // the accumulator wants the closest hit, not every intersection
     double t;
     int leaf;
 };
@@ -176,6 +177,7 @@ __device__ __forceinline__ void pin(Best &b) { asm volatile("" : "+v"(b.t), "+v"
 // nearer than `far`?  Which object it belongs to does not matter, and a lane that has its answer (any candidate
 // with 0 <= t < far settles it) needs no further range of nodes opened on its behalf.
 struct Occluded {
+    static constexpr bool every = false;
     double t;  // closest so far, as in Best
     double far;
 };
@@ -190,6 +192,30 @@ __device__ __forceinline__ void cand_ordered(bool oka, double ta, bool okb, doub
 __device__ __forceinline__ double hit_limit(const Occluded &b, double) { return b.far; }
 __device__ __forceinline__ bool settled(const Occluded &b) { return b.t < b.far; }
 __device__ __forceinline__ void pin(Occluded &b) { asm volatile("" : "+v"(b.t)); }
+
+// World::intersect itself (rendering/world.rs:27-36): every intersection the reference pushes, in the order it pushes
+// them (negative and NaN t's included), into the lane's own slice of the output; `count` keeps counting past `cap` so
+// that the caller learns the size it needs.
+struct AllHits {
+    static constexpr bool every = true;
+    double *t;
+    int *leaf;
+    unsigned cap, count;
+};
+__device__ __forceinline__ void cand(bool ok, double t, int leaf, AllHits &b) {
+    if (ok) {
+        if (b.count < b.cap) {
+            b.t[b.count] = t;
+            b.leaf[b.count] = leaf;
+        }
+        b.count++;
+    }
+}
+__device__ __forceinline__ void cand_ordered(bool oka, double ta, bool okb, double tb, int leaf, AllHits &b) {
+    cand(oka, ta, leaf, b);
+    cand(okb, tb, leaf, b);
+}
+__device__ __forceinline__ void pin(AllHits &) {}
 
 // geometry/cubes.rs:41-59 (threshold EPSILON, extents -1..1) and geometry/bounds.rs:110-128 (threshold 1e-10)
 __device__ __forceinline__ void check_axis(double origin, double direction, double lo, double hi, double threshold,
@@ -232,8 +258,12 @@ __device__ __forceinline__ bool hit_sphere(V3 o, V3 d, bool on, int leaf, B &bes
     double den = 2.0 * a;
     // The far root can only be the closest hit when the near one is negative (or NaN): most rays never need it.
     double t = (-b - sq) / den;
-    if (on && !(t >= 0.0)) t = (-b + sq) / den;
-    cand(on, t, leaf, best);
+    if constexpr (B::every) {
+        cand_ordered(on, t, on, (-b + sq) / den, leaf, best);
+    } else {
+        if (on && !(t >= 0.0)) t = (-b + sq) / den;
+        cand(on, t, leaf, best);
+    }
     return true;
 }
 
@@ -296,7 +326,7 @@ __device__ __forceinline__ bool wall_roots(V3 o, V3 d, double b, double sq, doub
     double y0 = o.y + ta * d.y;
     const bool in0 = minimum < y0 && y0 < maximum;
     bool in1 = false;
-    if (COUNT || (on && !(in0 && ta >= 0.0))) {  // the larger root matters only when the smaller is no hit
+    if (COUNT || B::every || (on && !(in0 && ta >= 0.0))) {  // the larger root matters only when the smaller is no hit
         double tb = (swap ? (-b - sq) : (-b + sq)) / den;
         double y1 = o.y + tb * d.y;
         in1 = minimum < y1 && y1 < maximum;
@@ -447,7 +477,7 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
         V3 lo = o, ld = d;
         bool shortcut = false;  // a cone below this range-skip node takes the reference's linear shortcut for this ray
         if (WIDE && kind == RT_SKIPBOX) {
-            if constexpr (WIDE && !STATS) {
+            if constexpr (WIDE && !STATS && !B::every) {
                 if (xform == RT_SKIP_CONES) {
                     double m[7];
 #pragma unroll
@@ -469,12 +499,12 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
         }
         // The record to have ready next: the following one -- except after a range-skip node, which more often
         // than not sends the traversal to `skip` (the table has one spare record at its end).
-        const int guess = (WIDE && kind == RT_SKIPBOX && !STATS) ? skip : i + 1;
+        const int guess = (WIDE && kind == RT_SKIPBOX && !STATS && !B::every) ? skip : i + 1;
         NodeRaw nraw = node_fetch<WIDE>(S.nodes + guess);
         int ni = i + 1;
         RT_NODE_VISIT(kind == RT_SKIPBOX ? 0 : kind == RT_GROUP ? 1 : 2);
         if (WIDE && kind == RT_SKIPBOX) {
-            if constexpr (WIDE && !STATS) {  // the counting kernel visits everything the reference visits
+            if constexpr (WIDE && !STATS && !B::every) {  // the counting kernel visits everything the reference visits
                 if (!have_inv) {
                     inv_d = mk(__builtin_amdgcn_rcp(d.x), __builtin_amdgcn_rcp(d.y), __builtin_amdgcn_rcp(d.z));
                     dmax = fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z));
@@ -1058,6 +1088,161 @@ __global__ __launch_bounds__(256) void intersect_kernel(DeviceScene scene, const
     }
 }
 
+// World::intersect (rendering/world.rs:27-36) for one ray per lane: every intersection, stably sorted by t.  Lane i
+// owns t[i*cap .. (i+1)*cap) and object[...]; count[i] is the number the reference's list would hold (the lists are
+// only complete when it is <= cap).  The sort is an insertion sort: stable, and with `<` on a list free of NaNs the
+// order is the one any stable sort by partial_cmp gives (world.rs:34).
+__global__ __launch_bounds__(256) void intersect_all_kernel(DeviceScene scene, const double *__restrict__ rays, unsigned n,
+                                                            unsigned cap, unsigned *__restrict__ count,
+                                                            double *__restrict__ t, int *__restrict__ object) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    SceneK S = scene_k(scene, 0);
+    Ctr<false> ctr;
+    V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+    AllHits all;
+    all.t = t + (size_t)(valid ? i : 0) * cap;
+    all.leaf = object + (size_t)(valid ? i : 0) * cap;
+    all.cap = valid ? cap : 0u;
+    all.count = 0u;
+    if (valid) {
+        ro = mk(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]);
+        rd = mk(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+    }
+    trace_range<0, RT_MAX_GROUP_NESTING, false, AllHits>(S, 0, S.n_nodes, ro, rd, valid, (double)INFINITY, all, ctr);
+    if (!valid) return;
+    count[i] = all.count;
+    const unsigned m = all.count < cap ? all.count : cap;
+    for (unsigned k = 0; k < m; ++k) all.leaf[k] = S.surfaces[all.leaf[k]].object;
+    for (unsigned k = 1; k < m; ++k) {
+        const double tk = all.t[k];
+        const int ok = all.leaf[k];
+        unsigned j = k;
+        while (j > 0 && tk < all.t[j - 1]) {
+            all.t[j] = all.t[j - 1];
+            all.leaf[j] = all.leaf[j - 1];
+            --j;
+        }
+        all.t[j] = tk;
+        all.leaf[j] = ok;
+    }
+}
+
+__device__ __forceinline__ V3 load3(const double *p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ void store3(double *p, V3 v) {
+    p[0] = v.x;
+    p[1] = v.y;
+    p[2] = v.z;
+}
+
+// The geometric half of Intersection::prepare_computations_for_intersections (rendering/intersections.rs:51-63) for
+// hit i = (comps[i].time, surface comps[i].object) on rays[i]; time, object, n1 and n2 are the caller's.
+__global__ __launch_bounds__(256) void prepare_computations_kernel(DeviceScene scene, const double *__restrict__ rays,
+                                                                   unsigned n, RtComps *__restrict__ comps) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    RtComps &c = comps[i];
+    const V3 ro = load3(rays + i * 6), rd = load3(rays + i * 6 + 3);
+    const V3 point = ro + rd * c.time;  // Ray::position (rendering/rays.rs:18-20)
+    V3 object_point;
+    V3 normal = normal_at(scene.surfaces + c.object, point, object_point);
+    const V3 eye = -rd;
+    const bool inside = dot(normal, eye) < 0.0;
+    if (inside) normal = -normal;
+    c.inside = inside ? 1 : 0;
+    store3(c.point, point);
+    store3(c.eye_vector, eye);
+    store3(c.normal_vector, normal);
+    store3(c.reflect_vector, reflect(rd, normal));
+    store3(c.over_point, point + normal * EPS);
+    store3(c.under_point, point - normal * EPS);
+}
+
+// Computations::schlick (rendering/intersections.rs:123-136)
+__device__ __forceinline__ double schlick(V3 eye, V3 normal, double n1, double n2) {
+    double c = dot(eye, normal);
+    if (n1 > n2) {
+        const double n = n1 / n2;
+        const double sin2_t = (n * n) * (1.0 - c * c);
+        if (sin2_t > 1.0) return 1.0;
+        c = sqrt(1.0 - sin2_t);
+    }
+    const double q = (n1 - n2) / (n1 + n2);
+    const double r0 = q * q;
+    const double m = 1.0 - c;
+    const double m2 = m * m;
+    return r0 + (1.0 - r0) * (m * (m2 * m2));
+}
+
+// World::shade_hit_internal, reflected_color_internal and refracted_color_internal (rendering/world.rs:84-111,
+// 155-168, 174-198) on caller-made Computations, which is how the reference's own tests reach them: the first level
+// uses the record's n1 / n2 and the nested sum of world.rs:107-110 as written; the rays it spawns go through
+// color_at like any other ray.
+template <int PART, int NEST>
+__global__ __launch_bounds__(256) void shade_part_kernel(DeviceScene scene, const RtComps *__restrict__ comps, unsigned n,
+                                                         int remaining, double *__restrict__ colors) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    SceneK S = scene_k(scene, remaining);
+    Ctr<false> ctr;
+    const RtComps &c = comps[valid ? i : 0];
+    const RtSurface *s = S.surfaces + c.object;
+    const V3 eye = load3(c.eye_vector), normal = load3(c.normal_vector);
+    const bool lit_world = S.light.has_light != 0;
+
+    V3 surface = mk(0.0, 0.0, 0.0);
+    if (PART == RT_PART_SHADE_HIT) {
+        const V3 over = load3(c.over_point), point = load3(c.point);
+        const V3 v = mk(S.light.position[0], S.light.position[1], S.light.position[2]) - over;  // world.rs:136-138
+        const double distance = magnitude(v);
+        const bool in_shadow = occluded<NEST, false>(S, over, div_by_magnitude(v, distance), valid && lit_world, distance, ctr);
+        if (valid && lit_world) {
+            V3 shadowed, lit;
+            int flags;
+            lighting<false>(s, S.light, point, mul_point(s->inv_world, point), eye, normal, shadowed, lit, flags, ctr);
+            surface = in_shadow ? shadowed : lit;
+        }
+    }
+
+    V3 reflected = mk(0.0, 0.0, 0.0);
+    if (PART != RT_PART_REFRACTED) {
+        const bool go = valid && remaining != 0 && s->reflectivity != 0.0 && (PART != RT_PART_SHADE_HIT || lit_world);
+        V3 child;
+        radiance<NEST, false>(S, go, load3(c.over_point), load3(c.reflect_vector), remaining - 1, child, ctr);
+        if (go) reflected = child * s->reflectivity;
+    }
+
+    V3 refracted = mk(0.0, 0.0, 0.0);
+    if (PART != RT_PART_REFLECTED) {
+        bool go = valid && remaining != 0 && s->transparency != 0.0 && (PART != RT_PART_SHADE_HIT || lit_world);
+        const double n_ratio = c.n1 / c.n2;
+        const double cos_i = dot(eye, normal);
+        const double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+        if (sin2_t > 1.0) go = false;
+        const double cos_t = sqrt(1.0 - sin2_t);
+        const V3 direction = normal * (n_ratio * cos_i - cos_t) - eye * n_ratio;
+        V3 child;
+        radiance<NEST, false>(S, go, load3(c.under_point), direction, remaining - 1, child, ctr);
+        if (go) refracted = child * s->transparency;
+    }
+
+    if (!valid) return;
+    V3 out;
+    if (PART == RT_PART_REFLECTED) {
+        out = reflected;
+    } else if (PART == RT_PART_REFRACTED) {
+        out = refracted;
+    } else if (!lit_world) {
+        out = mk(0.0, 0.0, 0.0);  // world.rs:86-89
+    } else if (s->reflectivity > 0.0 && s->transparency > 0.0) {
+        const double reflectance = schlick(eye, normal, c.n1, c.n2);
+        out = (surface + reflected * reflectance) + refracted * (1.0 - reflectance);
+    } else {
+        out = (surface + reflected) + refracted;
+    }
+    store3(colors + (size_t)i * 3, out);
+}
+
 __global__ __launch_bounds__(256) void is_shadowed_kernel(DeviceScene scene, const double *__restrict__ points,
                                                           unsigned n, uint8_t *__restrict__ out) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1194,6 +1379,39 @@ hipError_t launch_intersect(const DeviceScene &scene, const double *rays, uint32
                             hipStream_t stream) {
     if (n == 0) return hipSuccess;
     intersect_kernel<<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, t, object);
+    return hipGetLastError();
+}
+
+hipError_t launch_intersect_all(const DeviceScene &scene, const double *rays, uint32_t n, uint32_t cap, uint32_t *count,
+                                double *t, int32_t *object, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    intersect_all_kernel<<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, cap, count, t, object);
+    return hipGetLastError();
+}
+
+hipError_t launch_prepare_computations(const DeviceScene &scene, const double *rays, uint32_t n, RtComps *comps,
+                                       hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    prepare_computations_kernel<<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, comps);
+    return hipGetLastError();
+}
+
+template <int PART>
+static void launch_part(const DeviceScene &scene, const RtComps *comps, uint32_t n, int remaining, double *colors, hipStream_t stream) {
+    const size_t lds = 4 * RAY_STACK_LDS_BYTES_PER_WAVE;
+    if (scene.max_nesting == 0) shade_part_kernel<PART, 0><<<blocks_for(n), 256, lds, stream>>>(scene, comps, n, remaining, colors);
+    else shade_part_kernel<PART, RT_MAX_GROUP_NESTING><<<blocks_for(n), 256, lds, stream>>>(scene, comps, n, remaining, colors);
+}
+
+hipError_t launch_shade_part(const DeviceScene &scene, int part, const RtComps *comps, uint32_t n, int remaining,
+                             double *colors, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    switch (part) {
+        case RT_PART_SHADE_HIT: launch_part<RT_PART_SHADE_HIT>(scene, comps, n, remaining, colors, stream); break;
+        case RT_PART_REFLECTED: launch_part<RT_PART_REFLECTED>(scene, comps, n, remaining, colors, stream); break;
+        case RT_PART_REFRACTED: launch_part<RT_PART_REFRACTED>(scene, comps, n, remaining, colors, stream); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

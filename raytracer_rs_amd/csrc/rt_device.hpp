@@ -46,6 +46,16 @@ hipError_t launch_color_at(const DeviceScene &scene, const double *rays, uint32_
 // World::intersect + Intersection::hit for n rays.
 hipError_t launch_intersect(const DeviceScene &scene, const double *rays, uint32_t n, double *t, int32_t *object,
                             hipStream_t stream);
+// World::intersect for n rays: all intersections, sorted; lane i fills slice i of t / object (cap entries each) and
+// count[i] (which may exceed cap: then the slice is incomplete).
+hipError_t launch_intersect_all(const DeviceScene &scene, const double *rays, uint32_t n, uint32_t cap, uint32_t *count,
+                                double *t, int32_t *object, hipStream_t stream);
+// Fills the vectors of n Computations whose time, object (a leaf index), n1 and n2 are set.
+hipError_t launch_prepare_computations(const DeviceScene &scene, const double *rays, uint32_t n, RtComps *comps,
+                                       hipStream_t stream);
+// World::shade_hit / reflected_color / refracted_color (RT_PART_*) of n Computations (object = leaf index).
+hipError_t launch_shade_part(const DeviceScene &scene, int part, const RtComps *comps, uint32_t n, int remaining,
+                             double *colors, hipStream_t stream);
 // World::is_shadowed for n points.
 hipError_t launch_is_shadowed(const DeviceScene &scene, const double *points, uint32_t n, uint8_t *out,
                               hipStream_t stream);

@@ -66,6 +66,17 @@ struct RtCameraDev {
     uint32_t hsize, vsize;
 };
 
+// Computations (rendering/intersections.rs:12-24) as the device kernels read and write it; the same layout as the
+// public rt_computations.  `object` is an index into RtSurface[] on the device side of the call.
+struct RtComps {
+    double time;
+    int32_t object;
+    int32_t inside;
+    double point[3], eye_vector[3], normal_vector[3], reflect_vector[3], over_point[3], under_point[3];
+    double n1, n2;
+};
+enum { RT_PART_SHADE_HIT = 0, RT_PART_REFLECTED = 1, RT_PART_REFRACTED = 2 };
+
 // Per-call counters; field order matches rt_stats (minus kernel_ms).
 struct RtCounters {
     unsigned long long rays, primary, shadow, reflect, refract;

@@ -60,6 +60,17 @@ def main():
     worst = int(np.argmax(life))
     print(f"longest wave: {iters[worst]:.0f} iterations, {lanes[worst] / iters[worst]:.1f} active lanes, {nodes[worst] / iters[worst]:.0f} nodes "
           f"per traversal, {trace[worst] / max(1.0, nodes[worst]):.0f} trace clocks per node, lifetime {life[worst] / 1e6:.1f} Mclk")
+    t0 = rbegin.min()
+    p99 = np.sort(rend)[int(0.99 * len(rend))]
+    tail = np.nonzero(rend > p99)[0]
+    tail = tail[np.argsort(-rend[tail])][:12]
+    print("the tail (last waves to end): start us / lifetime us / rounds / start rank in the launch")
+    rank = np.empty(len(order), dtype=np.int64)
+    rank[order] = np.arange(len(order))
+    for k in tail:
+        print(f"   {(rbegin[k] - t0) / 100:7.0f} {rlife[k] / 100:7.0f} {iters[k]:4.0f} {rank[k]:8d}")
+    started_late = np.nonzero((rend > p99) & (rbegin - t0 > 0.25 * (rend.max() - t0)))[0]
+    print(f"waves ending after the 99th percentile: {len(np.nonzero(rend > p99)[0])}, of which started after the first quarter of the launch: {len(started_late)}")
     tiles_x = (w + 7) // 8
     rows = life.reshape(-1, tiles_x).mean(axis=1)
     step = max(1, len(rows) // 18)
