@@ -26,6 +26,7 @@ struct rt_scene {
     unsigned long long *d_counters = nullptr;
     uint32_t *d_tiles = nullptr;  // tile-ordering scratch of launch_render, grown on demand
     size_t tiles_cap = 0;         // in 32-bit words
+    bool uneven = false;          // tiles differ in cost by more than a shadow ray: ordering them pays
     rt::DeviceScene dev;
     std::vector<int32_t> object_to_leaf;
     uint64_t device_bytes = 0;
@@ -200,6 +201,10 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     sc->dev.max_nesting = (int32_t)sc->flat.max_nesting;
     if (sc->flat.n_skip_nodes && sc->dev.max_nesting < 1) sc->dev.max_nesting = 1;
     sc->dev.light = sc->flat.light;
+    // In a flat scene without reflective or transparent surfaces every pixel costs one or two rays over the same
+    // few objects: nothing to gain from launching the tiles in any particular order.
+    sc->uneven = sc->dev.max_nesting > 0;
+    for (const RtSurface &s : sc->flat.surfaces) sc->uneven = sc->uneven || s.reflectivity != 0.0 || s.transparency != 0.0;
     *out = sc.release();
     return RT_OK;
 }
@@ -233,7 +238,7 @@ int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out) {
 static hipError_t tile_scratch(const rt_scene *scene_c, const rt_camera_desc *camera, const rt::RowMap &rows, uint32_t **out) {
     static const bool enabled = [] { const char *e = getenv("RT_TILE_ORDER"); return !(e && e[0] == '0'); }();
     *out = nullptr;
-    if (!enabled || rows.n_rows == 0) return hipSuccess;
+    if (!enabled || rows.n_rows == 0 || !scene_c->uneven) return hipSuccess;
     rt_scene *scene = const_cast<rt_scene *>(scene_c);
     const size_t need = rt::render_scratch_words(camera->hsize, rows.n_rows);
     if (need > scene->tiles_cap) {

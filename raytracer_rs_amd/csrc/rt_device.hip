@@ -960,15 +960,52 @@ __device__ __forceinline__ SceneK scene_k(const DeviceScene &d, int max_depth) {
 }
 
 // The frame is cut into 8x8 pixel tiles, one per wave, numbered row-major over the rows being rendered.
-// Tile cost classes, from the ray through the tile's centre: what it hits first (a miss costs one ray, a diffuse hit
-// two, a mirror or glass a whole tree) times how much of a deep scene it had to walk through.  Half-octave buckets
-// of that estimate; a launch hands out the expensive classes first so that its last waves are cheap ones.
-enum { TILE_CLASSES = 20, TILE_HEADER = 24 };
+//
+// A launch hands its tiles out in order of expected cost, most expensive first, so that its last waves are cheap
+// ones.  The estimate comes from the ray through the tile's centre (classify_tiles_kernel); tiles are then counting-
+// sorted by the quarter-octave of the estimate (order_count_kernel, order_scatter_kernel).  Scratch layout, in words:
+//   [0, 128)                 tiles per class           (cleared by the host before every launch)
+//   [128, 256)               tiles placed so far, per class (cleared likewise)
+//   [256 + 0*n, 256 + 1*n)   the tiles in launch order
+//   [256 + 1*n, 256 + 2*n)   cost estimate per tile
+//   [256 + 2*n, 256 + 3*n)   class per tile
+enum { TILE_CLASSES = 128, TILE_HEADER = 2 * TILE_CLASSES };
 __device__ __forceinline__ unsigned image_row(const RowMap &rows, unsigned r) {
     return rows.row_begin + (r / rows.band_rows) * rows.band_pitch + (r % rows.band_rows);
 }
+__device__ __forceinline__ size_t tile_cost_offset(unsigned n_tiles) { return TILE_HEADER + (size_t)n_tiles; }
+__device__ __forceinline__ size_t tile_class_offset(unsigned n_tiles) { return TILE_HEADER + 2 * (size_t)n_tiles; }
 
-// One lane per tile.  scratch[c] counts the tiles of class c; scratch[TILE_HEADER + c*n_tiles ...] lists them.
+// For every distinct key among the wave's `valid` lanes: one atomicAdd of the number of lanes holding it to
+// counters[key]; each lane gets the counter's previous value plus its rank among the lanes with the same key.
+__device__ __forceinline__ unsigned wave_aggregated_add(unsigned *counters, unsigned key, bool valid) {
+    const unsigned lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(valid);
+    unsigned slot = 0;
+    while (todo != 0ull) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned k = (unsigned)__shfl((int)key, leader, 64);
+        const unsigned long long same = __ballot(valid && key == k) & todo;
+        unsigned base = 0;
+        if ((int)lane == leader) base = atomicAdd(counters + k, (unsigned)__popcll(same));
+        base = (unsigned)__shfl((int)base, leader, 64);
+        if (valid && key == k) slot = base + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return slot;
+}
+
+// How deep the ray tree below a hit tends to be, by what was hit: rays refracted into a bounded shape bounce about
+// inside it, a transparent plane lets them go.
+__device__ __forceinline__ unsigned surface_weight(const SceneK &S, bool valid, const Best &hit) {
+    if (!valid || hit.leaf < 0) return 1u;
+    const RtSurface *s = S.surfaces + hit.leaf;
+    const bool traps = s->kind != RT_PLANE && s->transparency > 0.0;
+    if (traps) return s->reflectivity > 0.0 ? 24u : 12u;
+    return (s->transparency > 0.0 || s->reflectivity > 0.0) ? 6u : 2u;
+}
+
+// One lane per tile: the cost estimate of the tile from its centre ray.
 template <int NEST>
 __global__ __launch_bounds__(256) void classify_tiles_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows,
                                                              unsigned *__restrict__ scratch) {
@@ -982,26 +1019,82 @@ __global__ __launch_bounds__(256) void classify_tiles_kernel(DeviceScene scene, 
     Ctr<false> ctr;
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     if (valid) ray_for_pixel(cam, x, image_row(rows, r), ro, rd);
+    // What the centre ray meets, and what the reflection and the refraction ray of that hit meet: one level of the
+    // ray tree, no shading.  A floor tile that mirrors a glass ball is as deep as the ball.
     Best best = trace<NEST, false>(S, ro, rd, valid, (double)INFINITY, ctr);
-    unsigned weight = 1;
-    if (valid && best.leaf >= 0) {
-        const RtSurface *s = S.surfaces + best.leaf;
-        weight = s->transparency > 0.0 ? 12u : s->reflectivity > 0.0 ? 6u : 2u;
+    unsigned weight = surface_weight(S, valid, best);
+    const bool hit = valid && best.leaf >= 0;
+    const RtSurface *s = S.surfaces + (hit ? best.leaf : 0);
+    V3 over = ro, under = ro, reflected = rd, refracted = rd;
+    bool reflects = false, refracts = false;
+    if (hit) {
+        const V3 point = ro + rd * best.t;
+        V3 object_point;
+        V3 normal = normal_at(s, point, object_point);
+        const V3 eye = -rd;
+        if (dot(normal, eye) < 0.0) normal = -normal;
+        over = point + normal * EPS;
+        under = point - normal * EPS;
+        reflects = s->reflectivity != 0.0;
+        reflected = reflect(rd, normal);
+        if (s->transparency != 0.0) {  // world.rs:183-194 with n1 = 1, n2 = the object's index
+            const double n_ratio = 1.0 / s->refractive_index;
+            const double cos_i = dot(eye, normal);
+            const double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+            refracts = !(sin2_t > 1.0);
+            if (refracts) refracted = normal * (n_ratio * cos_i - sqrt(1.0 - sin2_t)) - eye * n_ratio;
+        }
     }
-    const unsigned cost = weight * (8u + ctr.visits);  // >= 8
-    const int lg = 31 - __clz((int)cost);
-    int cls = 2 * (lg - 3) + (int)((cost >> (lg - 1)) & 1u);
-    if (cls > TILE_CLASSES - 1) cls = TILE_CLASSES - 1;
-    const unsigned lane = threadIdx.x & 63;
-    for (int c = 0; c < TILE_CLASSES; ++c) {
-        const unsigned long long mask = __ballot(valid && cls == c);
-        if (mask == 0ull) continue;
-        unsigned base = 0;
-        if (lane == (unsigned)__ffsll((long long)mask) - 1u) base = atomicAdd(scratch + c, (unsigned)__popcll(mask));
-        base = __shfl(base, __ffsll((long long)mask) - 1, 64);
-        if (valid && cls == c)
-            scratch[TILE_HEADER + (size_t)c * rows.n_tiles + base + __popcll(mask & ((1ull << lane) - 1ull))] = tile;
+    if (__ballot(reflects) != 0ull) {
+        const Best child = trace<NEST, false>(S, over, reflected, reflects, (double)INFINITY, ctr);
+        if (reflects) weight += surface_weight(S, true, child);
     }
+    if (__ballot(refracts) != 0ull) {
+        const Best child = trace<NEST, false>(S, under, refracted, refracts, (double)INFINITY, ctr);
+        if (refracts) weight += surface_weight(S, true, child);
+    }
+    if (valid) scratch[tile_cost_offset(rows.n_tiles) + tile] = weight * (8u + ctr.visits);  // >= 8
+}
+
+// One lane per tile: the tile's class, from the largest estimate among the tile and its eight neighbours -- a tile
+// on the silhouette of a glass object is as slow as the slowest of its pixels (the grazing ones are the slowest of
+// all), whatever its centre ray met -- and the census of the classes.
+__global__ __launch_bounds__(256) void order_count_kernel(RowMap rows, unsigned tiles_x, unsigned *__restrict__ scratch) {
+    const unsigned tile = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = tile < rows.n_tiles;
+    const unsigned *cost_of = scratch + tile_cost_offset(rows.n_tiles);
+    unsigned cost = 8u;
+    if (valid) {
+        const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
+        const int tiles_y = (int)((rows.n_tiles + tiles_x - 1) / tiles_x);
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int nx = tx + dx, ny = ty + dy;
+                if (nx < 0 || ny < 0 || nx >= (int)tiles_x || ny >= tiles_y) continue;
+                const unsigned c = cost_of[(unsigned)ny * tiles_x + (unsigned)nx];
+                cost = c > cost ? c : cost;
+            }
+    }
+    const int lg = 31 - __clz((int)(cost | 8u));                        // 3 .. 31
+    const unsigned cls = 4u * (unsigned)(lg - 3) + ((cost >> (lg - 2)) & 3u);  // quarter octaves: 0 .. 115
+    if (valid) scratch[tile_class_offset(rows.n_tiles) + tile] = cls;
+    (void)wave_aggregated_add(scratch, cls, valid);
+}
+
+// One lane per tile: its place in the launch order -- after every tile of a more expensive class.
+__global__ __launch_bounds__(256) void order_scatter_kernel(RowMap rows, unsigned *__restrict__ scratch) {
+    __shared__ unsigned before[TILE_CLASSES];  // tiles in classes more expensive than c
+    if (threadIdx.x < TILE_CLASSES) {
+        unsigned sum = 0;
+        for (unsigned c = threadIdx.x + 1; c < TILE_CLASSES; ++c) sum += scratch[c];
+        before[threadIdx.x] = sum;
+    }
+    __syncthreads();
+    const unsigned tile = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = tile < rows.n_tiles;
+    const unsigned cls = valid ? scratch[tile_class_offset(rows.n_tiles) + tile] : 0u;
+    const unsigned slot = wave_aggregated_add(scratch + TILE_CLASSES, cls, valid);
+    if (valid) scratch[TILE_HEADER + before[cls] + slot] = tile;
 }
 
 // Camera::render (rendering/camera.rs:56-67) for the rows of `rows`: one wave per 8x8 pixel tile.
@@ -1010,17 +1103,9 @@ __global__ __launch_bounds__(256, 4) void render_kernel(DeviceScene scene, RtCam
                                                      double *__restrict__ rgb, unsigned long long *counters) {
     const unsigned lane = threadIdx.x & 63;
     unsigned tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (rows.tile_list) {  // the tile this wave renders, from the class lists, most expensive class first
+    if (rows.tile_list) {  // the tile this wave renders: the launch order lists the expensive ones first
         if (tile >= rows.n_tiles) return;
-        const unsigned RT_CONSTANT_AS *count = (const unsigned RT_CONSTANT_AS *)rows.tile_list;
-        unsigned rem = tile;
-        int c = TILE_CLASSES - 1;
-        for (; c > 0; --c) {
-            const unsigned n = count[c];
-            if (rem < n) break;
-            rem -= n;
-        }
-        tile = rows.tile_list[TILE_HEADER + (size_t)c * rows.n_tiles + rem];
+        tile = ((const unsigned RT_CONSTANT_AS *)rows.tile_list)[TILE_HEADER + tile];
     }
     const unsigned tiles_x = (cam.hsize + 7) >> 3;
     const unsigned x = (tile % tiles_x) * 8 + (lane & 7);
@@ -1329,7 +1414,7 @@ static void launch_render_nest(int nest, dim3 grid, unsigned block, hipStream_t 
 }
 
 size_t render_scratch_words(uint32_t hsize, uint32_t n_rows) {
-    return TILE_HEADER + (size_t)TILE_CLASSES * ((hsize + 7) / 8) * ((n_rows + 7) / 8);
+    return TILE_HEADER + 3 * (size_t)((hsize + 7) / 8) * ((n_rows + 7) / 8);
 }
 
 hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows_in, int max_depth,
@@ -1349,6 +1434,8 @@ hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, co
             case 2: classify_tiles_kernel<2><<<cgrid, 256, 0, stream>>>(scene, camera, rows, tile_scratch); break;
             default: classify_tiles_kernel<RT_MAX_GROUP_NESTING><<<cgrid, 256, 0, stream>>>(scene, camera, rows, tile_scratch); break;
         }
+        order_count_kernel<<<cgrid, 256, 0, stream>>>(rows, (camera.hsize + 7) / 8, tile_scratch);
+        order_scatter_kernel<<<cgrid, 256, 0, stream>>>(rows, tile_scratch);
         rows.tile_list = tile_scratch;
     }
     // One wave per workgroup: a finished wave's slot is refilled at once, without waiting for three more.

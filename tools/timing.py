@@ -27,10 +27,15 @@ def main():
     lib = _lib.lib()
     import numpy as np
 
-    n_waves = ((w + 7) // 8) * ((h + 7) // 8)
+    bands = None
+    rows_rendered = h
+    if os.environ.get("RT_TIMING_BANDS"):  # "band_rows,first,step": time one rank's share of a multi-GPU frame
+        bands = tuple(int(v) for v in os.environ["RT_TIMING_BANDS"].split(","))
+        rows_rendered = sum(min(bands[0], h - y) for y in range(bands[1] * bands[0], h, bands[0] * bands[2]))
+    n_waves = ((w + 7) // 8) * ((rows_rendered + 7) // 8)
     buf = np.zeros((n_waves, 6), dtype=np.uint64)
-    scene.render(cam)
-    img, st = scene.render(cam)
+    scene.render(cam, bands=bands)
+    img, st = scene.render(cam, bands=bands)
     lib.rt_debug_timing(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(n_waves))
     m32, m40 = np.uint64(0xFFFFFFFF), np.uint64((1 << 40) - 1)
     trace, shade = (buf[:, 0] & m32).astype(float), (buf[:, 0] >> np.uint64(32)).astype(float)
