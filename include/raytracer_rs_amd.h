@@ -121,8 +121,10 @@ typedef struct rt_render_opts {
      * rows and this call renders bands band_first, band_first + band_step, band_first + 2*band_step, ...
      * (row_begin/row_end are ignored).  band_rows = 0 renders the contiguous range above. */
     uint32_t band_rows, band_first, band_step;
-    uint32_t _pad;
+    uint32_t flags; /* RT_RENDER_* */
 } rt_render_opts;
+/* rt_render_device: record events round the launch so that rt_scene_render_times can report it (no synchronisation). */
+#define RT_RENDER_TIMED 1u
 
 typedef struct rt_scene_info {
     uint32_t n_objects, n_leaves, n_groups, max_nesting;
@@ -166,6 +168,11 @@ int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_rend
  * collect_stats is set. */
 int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
                      double *rgb_device, rt_stats *stats);
+
+/* Measurement aid, no counterpart in the reference: GPU time of a launch made with RT_RENDER_TIMED, `back` launches
+ * ago (0 = the latest; the handle remembers eight): the tile-ordering pass and the render kernel, in milliseconds.
+ * The caller must have synchronised the launch's stream first (RT_ERR_HIP otherwise). */
+int rt_scene_render_times(const rt_scene *scene, uint32_t back, double *ordering_ms, double *render_ms);
 
 /* World::color_at (rendering/world.rs:113-126) for n rays (6 doubles each: origin xyz, direction xyz) with the
  * given recursion budget (world.rs:117 `remaining`; pass RT_DEFAULT_DEPTH for color_at itself). */

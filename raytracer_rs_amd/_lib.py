@@ -20,6 +20,7 @@ SPHERE, PLANE, CUBE, CYLINDER, CONE, GROUP = range(6)
 PATTERN_NONE, PATTERN_STRIPE, PATTERN_GRADIENT, PATTERN_RING, PATTERN_CHECKERS = -1, 0, 1, 2, 3
 MAX_GROUP_NESTING = 3
 DEFAULT_DEPTH = 5
+RENDER_TIMED = 1
 MAX_DEPTH = 8
 
 
@@ -86,7 +87,7 @@ class Computations(C.Structure):
 class RenderOpts(C.Structure):
     _fields_ = [("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("max_depth", C.c_int32),
                 ("collect_stats", C.c_int32), ("stream", C.c_void_p), ("band_rows", C.c_uint32),
-                ("band_first", C.c_uint32), ("band_step", C.c_uint32), ("_pad", C.c_uint32)]
+                ("band_first", C.c_uint32), ("band_step", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class SceneInfo(C.Structure):
@@ -105,6 +106,7 @@ SIGNATURES = {
     "rt_scene_get_info": (C.c_int, [C.c_void_p, _P(SceneInfo)]),
     "rt_render": (C.c_int, [C.c_void_p, _P(CameraDesc), _P(RenderOpts), _P(C.c_double), _P(Stats)]),
     "rt_render_device": (C.c_int, [C.c_void_p, _P(CameraDesc), _P(RenderOpts), C.c_void_p, _P(Stats)]),
+    "rt_scene_render_times": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_double), _P(C.c_double)]),
     "rt_color_at": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_int32, _P(C.c_double), _P(Stats)]),
     "rt_intersect": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, _P(C.c_double), _P(C.c_int32)]),
     "rt_intersect_all": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_uint32, _P(C.c_uint32), _P(C.c_double),

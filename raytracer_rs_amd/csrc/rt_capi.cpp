@@ -27,6 +27,8 @@ struct rt_scene {
     uint32_t *d_tiles = nullptr;  // tile-ordering scratch of launch_render, grown on demand
     size_t tiles_cap = 0;         // in 32-bit words
     bool uneven = false;          // tiles differ in cost by more than a shadow ray: ordering them pays
+    hipEvent_t marks[8][3] = {};  // event triples of the launches made with RT_RENDER_TIMED, used round-robin
+    uint32_t timed_launches = 0;
     rt::DeviceScene dev;
     std::vector<int32_t> object_to_leaf;
     uint64_t device_bytes = 0;
@@ -217,6 +219,9 @@ void rt_scene_destroy(rt_scene *scene) {
         if (scene->d_surfaces) (void)hipFree(scene->d_surfaces);
         if (scene->d_counters) (void)hipFree(scene->d_counters);
         if (scene->d_tiles) (void)hipFree(scene->d_tiles);
+        for (auto &triple : scene->marks)
+            for (hipEvent_t ev : triple)
+                if (ev) (void)hipEventDestroy(ev);
     }
     delete scene;
 }
@@ -270,13 +275,34 @@ int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const 
     if (want_stats) HIP_TRY(hipMemsetAsync(scene->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), stream));
     uint32_t *tiles = nullptr;
     HIP_TRY(tile_scratch(scene, camera, rows, &tiles));
-    HIP_TRY(rt::launch_render(scene->dev, cam, rows, depth, rgb_device, want_stats ? scene->d_counters : nullptr, tiles, stream));
+    hipEvent_t *marks = nullptr;
+    if (opts && (opts->flags & RT_RENDER_TIMED)) {
+        rt_scene *mut = const_cast<rt_scene *>(scene);  // one render at a time per handle
+        marks = mut->marks[mut->timed_launches % 8];
+        for (int k = 0; k < 3; ++k)
+            if (!marks[k]) HIP_TRY(hipEventCreate(&marks[k]));
+        mut->timed_launches++;
+    }
+    HIP_TRY(rt::launch_render(scene->dev, cam, rows, depth, rgb_device, want_stats ? scene->d_counters : nullptr, tiles, stream, marks));
     if (want_stats) {
         unsigned long long c[RT_NUM_COUNTERS];
         HIP_TRY(hipMemcpyAsync(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         stats_from_counters(c, stats);
     }
+    return RT_OK;
+}
+
+int rt_scene_render_times(const rt_scene *scene, uint32_t back, double *ordering_ms, double *render_ms) {
+    if (!scene || !ordering_ms || !render_ms) return set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (back >= 8 || back >= scene->timed_launches)
+        return set_error(RT_ERR_INVALID_ARGUMENT, "no launch with RT_RENDER_TIMED that far back");
+    const hipEvent_t *marks = scene->marks[(scene->timed_launches - 1 - back) % 8];
+    float a = 0.f, b = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, marks[0], marks[1]));
+    HIP_TRY(hipEventElapsedTime(&b, marks[1], marks[2]));
+    *ordering_ms = a;
+    *render_ms = b;
     return RT_OK;
 }
 

@@ -1058,8 +1058,14 @@ __global__ __launch_bounds__(256) void classify_tiles_kernel(DeviceScene scene, 
 
 // One lane per tile: the tile's class, from the largest estimate among the tile and its eight neighbours -- a tile
 // on the silhouette of a glass object is as slow as the slowest of its pixels (the grazing ones are the slowest of
-// all), whatever its centre ray met -- and the census of the classes.
-__global__ __launch_bounds__(256) void order_count_kernel(RowMap rows, unsigned tiles_x, unsigned *__restrict__ scratch) {
+// all), whatever its centre ray met -- and the census of the classes.  Counts are gathered per workgroup in LDS
+// first: a frame has a handful of populated classes, and thousands of waves adding to the same few words of global
+// memory would queue up behind each other.
+enum { ORDER_BLOCK = 1024 };
+__global__ __launch_bounds__(ORDER_BLOCK) void order_count_kernel(RowMap rows, unsigned tiles_x, unsigned *__restrict__ scratch) {
+    __shared__ unsigned census[TILE_CLASSES];
+    if (threadIdx.x < TILE_CLASSES) census[threadIdx.x] = 0u;
+    __syncthreads();
     const unsigned tile = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = tile < rows.n_tiles;
     const unsigned *cost_of = scratch + tile_cost_offset(rows.n_tiles);
@@ -1078,22 +1084,31 @@ __global__ __launch_bounds__(256) void order_count_kernel(RowMap rows, unsigned 
     const int lg = 31 - __clz((int)(cost | 8u));                        // 3 .. 31
     const unsigned cls = 4u * (unsigned)(lg - 3) + ((cost >> (lg - 2)) & 3u);  // quarter octaves: 0 .. 115
     if (valid) scratch[tile_class_offset(rows.n_tiles) + tile] = cls;
-    (void)wave_aggregated_add(scratch, cls, valid);
+    (void)wave_aggregated_add(census, cls, valid);
+    __syncthreads();
+    if (threadIdx.x < TILE_CLASSES && census[threadIdx.x] != 0u) atomicAdd(scratch + threadIdx.x, census[threadIdx.x]);
 }
 
-// One lane per tile: its place in the launch order -- after every tile of a more expensive class.
-__global__ __launch_bounds__(256) void order_scatter_kernel(RowMap rows, unsigned *__restrict__ scratch) {
-    __shared__ unsigned before[TILE_CLASSES];  // tiles in classes more expensive than c
+// One lane per tile: its place in the launch order -- after every tile of a more expensive class.  A workgroup
+// reserves one run of places per class for all its tiles.
+__global__ __launch_bounds__(ORDER_BLOCK) void order_scatter_kernel(RowMap rows, unsigned *__restrict__ scratch) {
+    __shared__ unsigned before[TILE_CLASSES];  // tiles in classes more expensive than c, then + this workgroup's run
+    __shared__ unsigned mine[TILE_CLASSES];    // this workgroup's tiles of class c
     if (threadIdx.x < TILE_CLASSES) {
         unsigned sum = 0;
         for (unsigned c = threadIdx.x + 1; c < TILE_CLASSES; ++c) sum += scratch[c];
         before[threadIdx.x] = sum;
+        mine[threadIdx.x] = 0u;
     }
     __syncthreads();
     const unsigned tile = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = tile < rows.n_tiles;
     const unsigned cls = valid ? scratch[tile_class_offset(rows.n_tiles) + tile] : 0u;
-    const unsigned slot = wave_aggregated_add(scratch + TILE_CLASSES, cls, valid);
+    const unsigned slot = wave_aggregated_add(mine, cls, valid);
+    __syncthreads();
+    if (threadIdx.x < TILE_CLASSES && mine[threadIdx.x] != 0u)
+        before[threadIdx.x] += atomicAdd(scratch + TILE_CLASSES + threadIdx.x, mine[threadIdx.x]);
+    __syncthreads();
     if (valid) scratch[TILE_HEADER + before[cls] + slot] = tile;
 }
 
@@ -1418,12 +1433,17 @@ size_t render_scratch_words(uint32_t hsize, uint32_t n_rows) {
 }
 
 hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows_in, int max_depth,
-                         double *rgb, unsigned long long *counters, uint32_t *tile_scratch, hipStream_t stream) {
+                         double *rgb, unsigned long long *counters, uint32_t *tile_scratch, hipStream_t stream,
+                         hipEvent_t *marks) {
     if (rows_in.n_rows == 0 || camera.hsize == 0 || rows_in.band_rows == 0) return hipSuccess;
     const unsigned long long tiles = (unsigned long long)((camera.hsize + 7) / 8) * ((rows_in.n_rows + 7) / 8);
     if (tiles > 0x7fffffffull) return hipErrorInvalidValue;
     RowMap rows = rows_in;
     rows.n_tiles = (unsigned)tiles;
+    if (marks) {
+        hipError_t e = hipEventRecord(marks[0], stream);
+        if (e != hipSuccess) return e;
+    }
     if (tile_scratch) {
         hipError_t e = hipMemsetAsync(tile_scratch, 0, TILE_HEADER * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
@@ -1434,9 +1454,14 @@ hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, co
             case 2: classify_tiles_kernel<2><<<cgrid, 256, 0, stream>>>(scene, camera, rows, tile_scratch); break;
             default: classify_tiles_kernel<RT_MAX_GROUP_NESTING><<<cgrid, 256, 0, stream>>>(scene, camera, rows, tile_scratch); break;
         }
-        order_count_kernel<<<cgrid, 256, 0, stream>>>(rows, (camera.hsize + 7) / 8, tile_scratch);
-        order_scatter_kernel<<<cgrid, 256, 0, stream>>>(rows, tile_scratch);
+        const dim3 ogrid((rows.n_tiles + ORDER_BLOCK - 1) / ORDER_BLOCK);
+        order_count_kernel<<<ogrid, ORDER_BLOCK, 0, stream>>>(rows, (camera.hsize + 7) / 8, tile_scratch);
+        order_scatter_kernel<<<ogrid, ORDER_BLOCK, 0, stream>>>(rows, tile_scratch);
         rows.tile_list = tile_scratch;
+    }
+    if (marks) {
+        hipError_t e = hipEventRecord(marks[1], stream);
+        if (e != hipSuccess) return e;
     }
     // One wave per workgroup: a finished wave's slot is refilled at once, without waiting for three more.
     const dim3 grid(rows.n_tiles);
@@ -1445,7 +1470,9 @@ hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, co
         launch_render_nest<true>(scene.max_nesting, grid, block, stream, scene, camera, rows, max_depth, rgb, counters);
     else
         launch_render_nest<false>(scene.max_nesting, grid, block, stream, scene, camera, rows, max_depth, rgb, nullptr);
-    return hipGetLastError();
+    hipError_t launched = hipGetLastError();
+    if (launched == hipSuccess && marks) launched = hipEventRecord(marks[2], stream);
+    return launched;
 }
 
 hipError_t launch_color_at(const DeviceScene &scene, const double *rays, uint32_t n, int remaining, double *colors,

@@ -34,10 +34,13 @@ struct RowMap {
 size_t render_scratch_words(uint32_t hsize, uint32_t n_rows);
 // Camera::render over the rows of `rows`: rgb receives n_rows*hsize*3 doubles.
 // counters == nullptr launches the plain kernel; otherwise the counting variant adds into counters[RT_NUM_COUNTERS].
+// marks (three events, or nullptr) are recorded before the tile-ordering pass, between it and the render kernel, and
+// after the render kernel.
 // tile_scratch (render_scratch_words() words, or nullptr) lets the launch order its 8x8 pixel tiles by expected cost,
 // expensive first, which shortens the under-occupied end of the launch; the image does not depend on it.
 hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows, int max_depth,
-                         double *rgb, unsigned long long *counters, uint32_t *tile_scratch, hipStream_t stream);
+                         double *rgb, unsigned long long *counters, uint32_t *tile_scratch, hipStream_t stream,
+                         hipEvent_t *marks = nullptr);
 // The canvas quantiser (rendering/canvas.rs:123-130) over n values in device memory.
 hipError_t launch_quantize(const double *rgb, size_t n, uint8_t *out, hipStream_t stream);
 // World::color_at for n rays.
