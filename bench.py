@@ -141,23 +141,18 @@ def main() -> None:
     u8 = args.frame == "u8"
     bg = BandGather(W, H, rank, world_size, dev, BAND_ROWS, dtype=torch.uint8 if u8 else torch.float64)
     stream = torch.cuda.current_stream().cuda_stream
-    # with 8-bit collection the kernel still writes f64 colours; they are quantised into the buffer that is collected
-    f64_stage = torch.zeros((bg.n_bands if world_size == 1 else bg.slots, bg.band_vals), dtype=torch.float64, device=dev) if u8 else None
-
     def render_mine(k: int = 0, stats: bool = False, timed: bool = False):
         """Frame k: this rank's bands, rendered (and quantised) into the buffer the gather of frame k reads.
         `timed`: the library records HIP events on the launch's stream before the tile-ordering pass, between it and
         the render kernel and after the render kernel (no synchronisation); read back after the timed region."""
         target = bg.frame if world_size == 1 else bg.buffer(k)
-        out = f64_stage if u8 else target
         if world_size > 1:
             bg.begin_render(k)
+        # with 8-bit collection the render kernel quantises its own output (RT_RENDER_QUANTIZED)
         if world_size == 1:
-            st = scene.render_device(cam, out.data_ptr(), None, 0, stream, stats, timed)
+            st = scene.render_device(cam, target.data_ptr(), None, 0, stream, stats, timed, u8)
         else:
-            st = scene.render_device_bands(cam, out.data_ptr(), BAND_ROWS, rank, world_size, 0, stream, stats, timed)
-        if u8:
-            rt.quantize_device(out.data_ptr(), out.numel(), target.data_ptr(), stream)
+            st = scene.render_device_bands(cam, target.data_ptr(), BAND_ROWS, rank, world_size, 0, stream, stats, timed, u8)
         return st
 
     def step(k: int):
@@ -250,7 +245,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": f"{os.path.basename(args.scene)} at {W}x{H}, depth 5, {BAND_ROWS}-row bands "
                                    f"round-robin over {world_size} GPU(s), f64 colours -> "
-                                   + ("8-bit frame (quantised on the GPU, as Canvas::to_ppm does) " if u8 else "f64 frame ")
+                                   + ("8-bit frame (canvas.rs:123-130 applied by the render kernel) " if u8 else "f64 frame ")
                                    + "collected on rank 0",
                        "rays_per_frame": rays_frame, "rays_per_pixel": round(rays_frame / (W * H), 3),
                        "kernel_ms_max_over_ranks": round(kernel_ms_max, 4)},

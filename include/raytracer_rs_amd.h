@@ -125,6 +125,10 @@ typedef struct rt_render_opts {
 } rt_render_opts;
 /* rt_render_device: record events round the launch so that rt_scene_render_times can report it (no synchronisation). */
 #define RT_RENDER_TIMED 1u
+/* rt_render_device: store the frame as 8-bit values -- `rgb_device` then points at uint8_t[rows * hsize * 3] -- with the
+ * canvas quantiser (rendering/canvas.rs:123-130) applied by the render kernel itself; the same bytes as rendering
+ * doubles and running rt_canvas_quantize_device over them, without the f64 frame ever being written. */
+#define RT_RENDER_QUANTIZED 2u
 
 typedef struct rt_scene_info {
     uint32_t n_objects, n_leaves, n_groups, max_nesting;

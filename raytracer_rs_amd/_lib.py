@@ -21,6 +21,7 @@ PATTERN_NONE, PATTERN_STRIPE, PATTERN_GRADIENT, PATTERN_RING, PATTERN_CHECKERS =
 MAX_GROUP_NESTING = 3
 DEFAULT_DEPTH = 5
 RENDER_TIMED = 1
+RENDER_QUANTIZED = 2
 MAX_DEPTH = 8
 
 

@@ -324,7 +324,8 @@ class Scene:
         return a.value, b.value
 
     def render_device(self, camera: "Camera", device_ptr: int, rows: Optional[Tuple[int, int]] = None,
-                      max_depth: int = 0, stream: int = 0, stats: bool = False, timed: bool = False) -> Optional[L.Stats]:
+                      max_depth: int = 0, stream: int = 0, stats: bool = False, timed: bool = False,
+                      quantized: bool = False) -> Optional[L.Stats]:
         """rt_render_device: asynchronous launch on `stream` into device memory at `device_ptr`
         ((row_end-row_begin)*hsize*3 doubles)."""
         cd = camera._desc()
@@ -334,13 +335,14 @@ class Scene:
         opts.max_depth = max_depth
         opts.collect_stats = int(stats)
         opts.stream = C.c_void_p(stream)
-        opts.flags = L.RENDER_TIMED if timed else 0
+        opts.flags = (L.RENDER_TIMED if timed else 0) | (L.RENDER_QUANTIZED if quantized else 0)
         st = L.Stats()
         L.check(L.lib().rt_render_device(self._h, C.byref(cd), C.byref(opts), C.c_void_p(device_ptr), C.byref(st)))
         return st if stats else None
 
     def render_device_bands(self, camera: "Camera", device_ptr: int, band_rows: int, band_first: int, band_step: int,
-                            max_depth: int = 0, stream: int = 0, stats: bool = False, timed: bool = False) -> Optional[L.Stats]:
+                            max_depth: int = 0, stream: int = 0, stats: bool = False, timed: bool = False,
+                            quantized: bool = False) -> Optional[L.Stats]:
         """rt_render_device restricted to bands band_first, band_first+band_step, ... of band_rows rows each; the
         bands are written one after another at `device_ptr`."""
         cd = camera._desc()
@@ -349,7 +351,7 @@ class Scene:
         opts.max_depth = max_depth
         opts.collect_stats = int(stats)
         opts.stream = C.c_void_p(stream)
-        opts.flags = L.RENDER_TIMED if timed else 0
+        opts.flags = (L.RENDER_TIMED if timed else 0) | (L.RENDER_QUANTIZED if quantized else 0)
         st = L.Stats()
         L.check(L.lib().rt_render_device(self._h, C.byref(cd), C.byref(opts), C.c_void_p(device_ptr), C.byref(st)))
         return st if stats else None

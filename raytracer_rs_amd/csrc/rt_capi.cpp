@@ -107,6 +107,7 @@ int render_rows(const rt_scene *scene, const rt_camera_desc *camera, const rt_re
         if (opts->max_depth < 0 || opts->max_depth > RT_MAX_DEPTH)
             return set_error(RT_ERR_INVALID_ARGUMENT, "max_depth must be within 0.." + std::to_string(RT_MAX_DEPTH));
         depth = clamp_depth(opts->max_depth);
+        if (opts->flags & ~(RT_RENDER_TIMED | RT_RENDER_QUANTIZED)) return set_error(RT_ERR_INVALID_ARGUMENT, "unknown bits in flags");
         if (opts->band_rows) {
             if (opts->band_step == 0) return set_error(RT_ERR_INVALID_ARGUMENT, "band_step must be positive");
             const uint32_t n_bands = (camera->vsize + opts->band_rows - 1) / opts->band_rows;
@@ -275,6 +276,7 @@ int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const 
     if (want_stats) HIP_TRY(hipMemsetAsync(scene->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), stream));
     uint32_t *tiles = nullptr;
     HIP_TRY(tile_scratch(scene, camera, rows, &tiles));
+    if (opts && (opts->flags & RT_RENDER_QUANTIZED)) rows.quantized = reinterpret_cast<uint8_t *>(rgb_device);
     hipEvent_t *marks = nullptr;
     if (opts && (opts->flags & RT_RENDER_TIMED)) {
         rt_scene *mut = const_cast<rt_scene *>(scene);  // one render at a time per handle
@@ -314,6 +316,7 @@ int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_rend
     int rc = render_rows(scene, camera, opts, rows, depth, cam);
     if (rc != RT_OK) return rc;
     if (!rgb) return set_error(RT_ERR_INVALID_ARGUMENT, "rgb must not be NULL");
+    if (opts && opts->flags) return set_error(RT_ERR_INVALID_ARGUMENT, "flags are for rt_render_device");
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (rows.n_rows == 0) return RT_OK;
     const bool want_stats = opts && opts->collect_stats;

@@ -959,12 +959,19 @@ __device__ __forceinline__ SceneK scene_k(const DeviceScene &d, int max_depth) {
     return S;
 }
 
+// convert_canvas_color_value_to_decimal_rgb_value (rendering/canvas.rs:123-130): (value * 255.0).round() as u32, then
+// min(255).  `round` is half-away-from-zero; the Rust cast saturates and maps NaN to 0.
+__device__ __forceinline__ unsigned quantize_value(double v) {
+    const double r = round(v * 255.0);
+    return !(r > 0.0) ? 0u : r >= 255.0 ? 255u : (unsigned)r;
+}
+
 // The frame is cut into 8x8 pixel tiles, one per wave, numbered row-major over the rows being rendered.
 //
 // A launch hands its tiles out in order of expected cost, most expensive first, so that its last waves are cheap
 // ones.  The estimate comes from the ray through the tile's centre (classify_tiles_kernel); tiles are then counting-
 // sorted by the quarter-octave of the estimate (order_count_kernel, order_scatter_kernel).  Scratch layout, in words:
-//   [0, 128)                 tiles per class           (cleared by the host before every launch)
+//   [0, 128)                 tiles per class           (cleared by classify_tiles_kernel)
 //   [128, 256)               tiles placed so far, per class (cleared likewise)
 //   [256 + 0*n, 256 + 1*n)   the tiles in launch order
 //   [256 + 1*n, 256 + 2*n)   cost estimate per tile
@@ -1009,6 +1016,8 @@ __device__ __forceinline__ unsigned surface_weight(const SceneK &S, bool valid, 
 template <int NEST>
 __global__ __launch_bounds__(256) void classify_tiles_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows,
                                                              unsigned *__restrict__ scratch) {
+    static_assert(TILE_HEADER == 256, "the first workgroup clears the census and the cursors, one word per thread");
+    if (blockIdx.x == 0) scratch[threadIdx.x] = 0u;  // read by the kernels that follow this one
     const unsigned tile = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = tile < rows.n_tiles;
     const unsigned tiles_x = (cam.hsize + 7) >> 3;
@@ -1139,9 +1148,15 @@ __global__ __launch_bounds__(256, 4) void render_kernel(DeviceScene scene, RtCam
     radiance<NEST, STATS>(S, valid, ro, rd, max_depth, acc, ctr);
     if (valid) {
         size_t idx = ((size_t)r * cam.hsize + x) * 3;  // Canvas index (rendering/canvas.rs:40-42) within the rows rendered
-        rgb[idx] = acc.x;
-        rgb[idx + 1] = acc.y;
-        rgb[idx + 2] = acc.z;
+        if (rows.quantized) {
+            rows.quantized[idx] = quantize_value(acc.x);
+            rows.quantized[idx + 1] = quantize_value(acc.y);
+            rows.quantized[idx + 2] = quantize_value(acc.z);
+        } else {
+            rgb[idx] = acc.x;
+            rgb[idx + 1] = acc.y;
+            rgb[idx + 2] = acc.z;
+        }
     }
     flush_counters<STATS>(ctr, counters);
 }
@@ -1397,9 +1412,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict_
     unsigned q[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const double v = base + k < n ? rgb[base + k] : 0.0;
-        const double r = round(v * 255.0);
-        q[k] = !(r > 0.0) ? 0u : r >= 255.0 ? 255u : (unsigned)r;
+        q[k] = quantize_value(base + k < n ? rgb[base + k] : 0.0);
     }
     if (base + 8 <= n && (reinterpret_cast<size_t>(out + base) & 7) == 0) {
         uint2 w;
@@ -1445,8 +1458,6 @@ hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, co
         if (e != hipSuccess) return e;
     }
     if (tile_scratch) {
-        hipError_t e = hipMemsetAsync(tile_scratch, 0, TILE_HEADER * sizeof(uint32_t), stream);
-        if (e != hipSuccess) return e;
         const dim3 cgrid(blocks_for(rows.n_tiles));
         switch (scene.max_nesting) {
             case 0: classify_tiles_kernel<0><<<cgrid, 256, 0, stream>>>(scene, camera, rows, tile_scratch); break;

@@ -28,6 +28,8 @@ struct RowMap {
     uint32_t band_rows = 1, band_pitch = 0;
     uint32_t n_tiles = 0;                 // set by launch_render
     const uint32_t *tile_list = nullptr;  // set by launch_render
+    uint8_t *quantized = nullptr;         // when set, the frame is stored here as 8-bit values (3 bytes per pixel, the
+                                          // canvas quantiser applied in the kernel) and `rgb` is not written
 };
 
 // Number of 32-bit words of device scratch launch_render needs for a frame of hsize x n_rows pixels.

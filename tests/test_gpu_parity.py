@@ -547,6 +547,55 @@ def test_device_buffer_entry_point_and_band_packing(gpu, rt, orc):
         hip.hipFree(buf)
 
 
+def test_render_kernel_quantises_its_own_output(gpu, rt, orc):
+    """RT_RENDER_QUANTIZED: the 8-bit frame straight from the render kernel is the host quantiser (canvas.rs:123-130)
+    over the f64 frame, for whole frames, row ranges and bands; the launch can be timed (RT_RENDER_TIMED)."""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    for name, size in (("chapter_11", (203, 77)), ("chapter_10", (96, 64)), ("chapter_14", (120, 90))):
+        cam, world, _, _ = load_both(rt, orc, name, *size)
+        scene = world.scene()
+        full, _ = scene.render(cam)
+        expect = orc.quantize(full)
+        W, H = cam.hsize, cam.vsize
+        buf = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(buf), expect.size + 64) == 0
+        try:
+            def fetch(n_rows):
+                out = np.zeros(n_rows * W * 3 + 64, dtype=np.uint8)
+                assert hip.hipDeviceSynchronize() == 0
+                assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), buf, out.size, 2) == 0
+                assert not out[n_rows * W * 3:].any(), "wrote past the rows rendered"
+                return out[:n_rows * W * 3].reshape(n_rows, W, 3)
+
+            assert hip.hipMemset(buf, 0, expect.size + 64) == 0
+            scene.render_device(cam, buf.value, quantized=True, timed=True)
+            assert np.array_equal(fetch(H), expect)
+            ordering_ms, render_ms = scene.render_times()
+            assert 0.0 <= ordering_ms < 50.0 and 0.0 < render_ms < 500.0
+            assert hip.hipMemset(buf, 0, expect.size + 64) == 0
+            scene.render_device(cam, buf.value, rows=(10, 45), quantized=True)
+            assert np.array_equal(fetch(35), expect[10:45])
+            assert hip.hipMemset(buf, 0, expect.size + 64) == 0
+            scene.render_device_bands(cam, buf.value, 16, 1, 2, quantized=True)
+            bands = list(range(1, (H + 15) // 16, 2))
+            rows = sum(min(H, (b + 1) * 16) - b * 16 for b in bands)
+            got, at = fetch(rows), 0
+            for b in bands:
+                y0, y1 = b * 16, min(H, (b + 1) * 16)
+                assert np.array_equal(got[at:at + y1 - y0], expect[y0:y1])
+                at += y1 - y0
+        finally:
+            hip.hipFree(buf)
+    with pytest.raises(rt.RtError):  # no timed launch on this handle yet
+        load_both(rt, orc, "chapter_6")[1].scene().render_times()
+
+
 @pytest.mark.parametrize("size", [(1, 1), (17, 9), (33, 65), (64, 1), (1, 40), (250, 130)])
 def test_odd_frame_sizes(gpu, rt, orc, size):
     cam, world, ocam, oworld = load_both(rt, orc, "chapter_13", *size)
