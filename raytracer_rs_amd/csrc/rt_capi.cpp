@@ -203,6 +203,7 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     // range-skip nodes need the kernels that fetch whole node records, i.e. those built for at least one group level
     sc->dev.max_nesting = (int32_t)sc->flat.max_nesting;
     if (sc->flat.n_skip_nodes && sc->dev.max_nesting < 1) sc->dev.max_nesting = 1;
+    sc->dev.any_order = sc->flat.reordered ? 1 : 0;
     sc->dev.light = sc->flat.light;
     // In a flat scene without reflective or transparent surfaces every pixel costs one or two rays over the same
     // few objects: nothing to gain from launching the tiles in any particular order.

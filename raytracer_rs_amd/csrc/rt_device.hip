@@ -153,25 +153,42 @@ struct SceneK {
 // `t` starts as NaN: `!(x >= NaN)` holds for every x, so the first non-negative candidate (even +infinity) is taken,
 // and from then on t is an ordinary number and `!(x >= t)` is `x < t`.  Candidates arrive in the reference's emission
 // order, so the strict comparison keeps the earliest of equal t's.  Written with selects: no branch per candidate.
-struct Best {
+//
+// TIES: the node table of a scene with range-skip nodes lists long sibling lists in spatial order, not in the
+// reference's (rt_flatten.cpp), so "earliest emitted" is no longer "first met".  Leaves are numbered in the
+// reference's order whatever the table's, so among equal t's the smaller leaf number is the earlier emission.
+template <bool TIES>
+struct Closest {
     static constexpr bool every = false;  // the accumulator wants the closest hit, not every intersection
     double t;
     int leaf;
 };
-__device__ __forceinline__ void cand(bool ok, double t, int leaf, Best &b) {
-    const bool better = ok & (t >= 0.0) & !(t >= b.t);
+template <bool TIES>
+__device__ __forceinline__ void cand(bool ok, double t, int leaf, Closest<TIES> &b) {
+    bool nearer = !(t >= b.t);
+    if constexpr (TIES) nearer |= (t == b.t) & (leaf < b.leaf);
+    const bool better = ok & (t >= 0.0) & nearer;
     b.t = better ? t : b.t;
     b.leaf = better ? leaf : b.leaf;
 }
 // Two candidates of ONE object with ta <= tb (or a NaN among them), emitted ta first: the later one can only win
 // when the earlier one is not eligible, so one update does for both.
-__device__ __forceinline__ void cand_ordered(bool oka, double ta, bool okb, double tb, int leaf, Best &b) {
+template <bool TIES>
+__device__ __forceinline__ void cand_ordered(bool oka, double ta, bool okb, double tb, int leaf, Closest<TIES> &b) {
     const bool first = oka & (ta >= 0.0);
     cand(first | okb, first ? ta : tb, leaf, b);
 }
-__device__ __forceinline__ double hit_limit(const Best &b, double far) { return fmin(b.t, far); }
-__device__ __forceinline__ bool settled(const Best &) { return false; }
-__device__ __forceinline__ void pin(Best &b) { asm volatile("" : "+v"(b.t), "+v"(b.leaf)); }
+template <bool TIES>
+__device__ __forceinline__ double hit_limit(const Closest<TIES> &b, double far) { return fmin(b.t, far); }
+template <bool TIES>
+__device__ __forceinline__ bool settled(const Closest<TIES> &) { return false; }
+template <bool TIES>
+__device__ __forceinline__ void pin(Closest<TIES> &b) { asm volatile("" : "+v"(b.t), "+v"(b.leaf)); }
+// The kernels built for flat scenes without range-skip nodes (NEST == 0) always meet the objects in the reference's
+// order; of the others, the render kernel exists in both forms (the host knows whether it reordered anything) and
+// the rest assume it did.
+template <int NEST>
+constexpr bool ANY_ORDER = NEST > 0;
 
 // What World::is_shadowed (rendering/world.rs:128-149) asks of the same traversal: is the closest hit with t >= 0
 // nearer than `far`?  Which object it belongs to does not matter, and a lane that has its answer (any candidate
@@ -564,13 +581,13 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
     }
 }
 
-template <int NEST, bool STATS>
-__device__ __forceinline__ Best trace(const SceneK &S, V3 o, V3 d, bool active, double far, Ctr<STATS> &ctr) {
-    Best best;
+template <int NEST, bool STATS, bool TIES = ANY_ORDER<NEST>>
+__device__ __forceinline__ Closest<TIES> trace(const SceneK &S, V3 o, V3 d, bool active, double far, Ctr<STATS> &ctr) {
+    Closest<TIES> best;
     best.t = __builtin_nan("");
     best.leaf = -1;
     if (STATS && active) ctr.add(C_RAYS);
-    trace_range<0, NEST, STATS, Best>(S, 0, S.n_nodes, o, d, active, far, best, ctr);
+    trace_range<0, NEST, STATS, Closest<TIES>>(S, 0, S.n_nodes, o, d, active, far, best, ctr);
     return best;
 }
 
@@ -734,7 +751,7 @@ __device__ __forceinline__ void ray_for_pixel(const RtCameraDev &cam, unsigned p
 // next ray from the stack.  All lanes of a wave are thus always in the same phase: the two traversals never mix
 // scattered radiance rays with the coherent shadow rays, and the shading code runs once per round.  A lane whose
 // ray missed simply sits out the shadow traversal.
-template <int NEST, bool STATS>
+template <int NEST, bool STATS, bool TIES = ANY_ORDER<NEST>>
 __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 rd, int remaining0, V3 &acc,
                                          Ctr<STATS> &ctr) {
     bool have = valid;  // (ro, rd, w, remaining) is a radiance ray to trace
@@ -788,7 +805,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
 #endif
     while (__ballot(have) != 0ull) {
         RT_TIC(tm0);
-        const Best best = trace<NEST, STATS>(S, ro, rd, have, (double)INFINITY, ctr);
+        const Closest<TIES> best = trace<NEST, STATS, TIES>(S, ro, rd, have, (double)INFINITY, ctr);
         RT_TIC(tm1);
         const bool shade = have && best.leaf >= 0 && S.light.has_light;  // else black: world.rs:124, world.rs:86-89
         V3 acc_lit = acc;         // the sum if the hit is not in shadow (acc: if it is)
@@ -1004,7 +1021,8 @@ __device__ __forceinline__ unsigned wave_aggregated_add(unsigned *counters, unsi
 
 // How deep the ray tree below a hit tends to be, by what was hit: rays refracted into a bounded shape bounce about
 // inside it, a transparent plane lets them go.
-__device__ __forceinline__ unsigned surface_weight(const SceneK &S, bool valid, const Best &hit) {
+template <bool TIES>
+__device__ __forceinline__ unsigned surface_weight(const SceneK &S, bool valid, const Closest<TIES> &hit) {
     if (!valid || hit.leaf < 0) return 1u;
     const RtSurface *s = S.surfaces + hit.leaf;
     const bool traps = s->kind != RT_PLANE && s->transparency > 0.0;
@@ -1030,7 +1048,7 @@ __global__ __launch_bounds__(256) void classify_tiles_kernel(DeviceScene scene, 
     if (valid) ray_for_pixel(cam, x, image_row(rows, r), ro, rd);
     // What the centre ray meets, and what the reflection and the refraction ray of that hit meet: one level of the
     // ray tree, no shading.  A floor tile that mirrors a glass ball is as deep as the ball.
-    Best best = trace<NEST, false>(S, ro, rd, valid, (double)INFINITY, ctr);
+    const Closest<false> best = trace<NEST, false, false>(S, ro, rd, valid, (double)INFINITY, ctr);
     unsigned weight = surface_weight(S, valid, best);
     const bool hit = valid && best.leaf >= 0;
     const RtSurface *s = S.surfaces + (hit ? best.leaf : 0);
@@ -1055,11 +1073,11 @@ __global__ __launch_bounds__(256) void classify_tiles_kernel(DeviceScene scene, 
         }
     }
     if (__ballot(reflects) != 0ull) {
-        const Best child = trace<NEST, false>(S, over, reflected, reflects, (double)INFINITY, ctr);
+        const Closest<false> child = trace<NEST, false, false>(S, over, reflected, reflects, (double)INFINITY, ctr);
         if (reflects) weight += surface_weight(S, true, child);
     }
     if (__ballot(refracts) != 0ull) {
-        const Best child = trace<NEST, false>(S, under, refracted, refracts, (double)INFINITY, ctr);
+        const Closest<false> child = trace<NEST, false, false>(S, under, refracted, refracts, (double)INFINITY, ctr);
         if (refracts) weight += surface_weight(S, true, child);
     }
     if (valid) scratch[tile_cost_offset(rows.n_tiles) + tile] = weight * (8u + ctr.visits);  // >= 8
@@ -1122,7 +1140,7 @@ __global__ __launch_bounds__(ORDER_BLOCK) void order_scatter_kernel(RowMap rows,
 }
 
 // Camera::render (rendering/camera.rs:56-67) for the rows of `rows`: one wave per 8x8 pixel tile.
-template <bool STATS, int NEST>
+template <bool STATS, int NEST, bool TIES>
 __global__ __launch_bounds__(256, 4) void render_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth,
                                                      double *__restrict__ rgb, unsigned long long *counters) {
     const unsigned lane = threadIdx.x & 63;
@@ -1145,7 +1163,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel(DeviceScene scene, RtCam
         ctr.add(C_PRIMARY);
     }
     V3 acc;
-    radiance<NEST, STATS>(S, valid, ro, rd, max_depth, acc, ctr);
+    radiance<NEST, STATS, TIES>(S, valid, ro, rd, max_depth, acc, ctr);
     if (valid) {
         size_t idx = ((size_t)r * cam.hsize + x) * 3;  // Canvas index (rendering/canvas.rs:40-42) within the rows rendered
         if (rows.quantized) {
@@ -1196,7 +1214,7 @@ __global__ __launch_bounds__(256) void intersect_kernel(DeviceScene scene, const
         ro = mk(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]);
         rd = mk(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
     }
-    Best best = trace<RT_MAX_GROUP_NESTING, false>(S, ro, rd, valid, (double)INFINITY, ctr);
+    const Closest<true> best = trace<RT_MAX_GROUP_NESTING, false>(S, ro, rd, valid, (double)INFINITY, ctr);
     if (valid) {
         t[i] = best.leaf >= 0 ? best.t : __builtin_nan("");
         object[i] = best.leaf >= 0 ? S.surfaces[best.leaf].object : -1;
@@ -1205,8 +1223,9 @@ __global__ __launch_bounds__(256) void intersect_kernel(DeviceScene scene, const
 
 // World::intersect (rendering/world.rs:27-36) for one ray per lane: every intersection, stably sorted by t.  Lane i
 // owns t[i*cap .. (i+1)*cap) and object[...]; count[i] is the number the reference's list would hold (the lists are
-// only complete when it is <= cap).  The sort is an insertion sort: stable, and with `<` on a list free of NaNs the
-// order is the one any stable sort by partial_cmp gives (world.rs:34).
+// only complete when it is <= cap).  The sort is an insertion sort by (t, object): among equal t's the reference's
+// stable sort (world.rs:34) keeps its emission order, which is object order (the node table may list siblings in
+// another order), and within one object the order of emission, which the traversal keeps.
 __global__ __launch_bounds__(256) void intersect_all_kernel(DeviceScene scene, const double *__restrict__ rays, unsigned n,
                                                             unsigned cap, unsigned *__restrict__ count,
                                                             double *__restrict__ t, int *__restrict__ object) {
@@ -1233,7 +1252,7 @@ __global__ __launch_bounds__(256) void intersect_all_kernel(DeviceScene scene, c
         const double tk = all.t[k];
         const int ok = all.leaf[k];
         unsigned j = k;
-        while (j > 0 && tk < all.t[j - 1]) {
+        while (j > 0 && (tk < all.t[j - 1] || (tk == all.t[j - 1] && ok < all.leaf[j - 1]))) {
             all.t[j] = all.t[j - 1];
             all.leaf[j] = all.leaf[j - 1];
             --j;
@@ -1433,12 +1452,18 @@ inline unsigned blocks_for(unsigned n) { return (n + 255u) / 256u; }
 template <bool STATS>
 static void launch_render_nest(int nest, dim3 grid, unsigned block, hipStream_t stream, const DeviceScene &scene, const RtCameraDev &camera,
                                const RowMap &rows, int max_depth, double *rgb, unsigned long long *counters) {
+    const size_t lds = (block / 64) * RAY_STACK_LDS_BYTES_PER_WAVE;
+    // The counting variant always breaks ties by leaf number (right for any table order); the plain one does so
+    // only when the host reordered a sibling list, because the comparison is paid per candidate.
+    const bool ties = STATS || scene.any_order != 0;
+#define RT_LAUNCH(N, T) render_kernel<STATS, N, T><<<grid, block, lds, stream>>>(scene, camera, rows, max_depth, rgb, counters)
     switch (nest) {
-        case 0: render_kernel<STATS, 0><<<grid, block, (block / 64) * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
-        case 1: render_kernel<STATS, 1><<<grid, block, (block / 64) * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
-        case 2: render_kernel<STATS, 2><<<grid, block, (block / 64) * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
-        default: render_kernel<STATS, RT_MAX_GROUP_NESTING><<<grid, block, (block / 64) * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, camera, rows, max_depth, rgb, counters); break;
+        case 0: RT_LAUNCH(0, false); break;
+        case 1: if (ties) RT_LAUNCH(1, true); else RT_LAUNCH(1, STATS); break;
+        case 2: if (ties) RT_LAUNCH(2, true); else RT_LAUNCH(2, STATS); break;
+        default: if (ties) RT_LAUNCH(RT_MAX_GROUP_NESTING, true); else RT_LAUNCH(RT_MAX_GROUP_NESTING, STATS); break;
     }
+#undef RT_LAUNCH
 }
 
 size_t render_scratch_words(uint32_t hsize, uint32_t n_rows) {

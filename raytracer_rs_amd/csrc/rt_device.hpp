@@ -15,7 +15,7 @@ struct DeviceScene {
     int32_t n_nodes = 0;
     int32_t n_leaves = 0;
     int32_t max_nesting = 0;  // deepest nesting level of any node (0: no groups)
-    int32_t _pad = 0;
+    int32_t any_order = 0;    // non-zero: some sibling list of the table is not in the reference's order
     RtLight light{};
 };
 

@@ -12,8 +12,10 @@
 // here as RT_ERR_NOT_INVERTIBLE instead of aborting.
 #include "rt_flatten.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 #include "rt_math.hpp"
 
@@ -140,6 +142,7 @@ struct Builder {
     std::vector<Bounds> own, in_parent;
     std::vector<ConeDirs> cones;  // per object, in its parent's space
     std::vector<std::vector<uint32_t>> kids;
+    std::vector<int32_t> leaf_id;  // per object: its number among the leaves in the reference's (depth-first) order
 
     bool fail(int c, const char *fmt, unsigned idx) {
         char buf[160];
@@ -171,6 +174,7 @@ struct Builder {
             next = child;
         } else {
             own[idx] = leaf_bounds(o);
+            leaf_id[idx] = (int32_t)out.n_leaves++;
             next = idx + 1;
         }
         const Matrix4 T = Matrix4::from_array(o.transformation);
@@ -222,6 +226,83 @@ struct Builder {
         for (int i = 0; i < 6; ++i) head.a[i] = box[i];
         out.nodes.push_back(head);
         out.n_skip_nodes++;
+    }
+
+    // Total surface area of the boxes emit_range() would put round the ranges of list[a..b) (all members bounded):
+    // a measure of how often rays will have to look inside them.
+    double boxes_area(const std::vector<uint32_t> &list, size_t a, size_t b, bool whole_list) const {
+        const size_t n = b - a;
+        if (n <= (whole_list ? SKIP_MIN_LIST : SKIP_RUN)) return 0.0;
+        const size_t parts = n > 4 * SKIP_RUN ? 4 : 2;
+        double total = 0.0;
+        for (size_t p = 0; p < parts; ++p) {
+            const size_t pa = a + n * p / parts, pb = a + n * (p + 1) / parts;
+            if (pb - pa >= 2) {
+                Bounds u = Bounds::empty();
+                for (size_t k = pa; k < pb; ++k) u = u.merge(in_parent[list[k]]);
+                const double dx = u.max.x - u.min.x, dy = u.max.y - u.min.y, dz = u.max.z - u.min.z;
+                total += dx * dy + dy * dz + dz * dx;
+            }
+            total += boxes_area(list, pa, pb, false);
+        }
+        return total;
+    }
+
+    // Siblings of a long list, reordered so that every range emit_range() will box is spatially compact: members
+    // without finite bounds first (no box can hold them), then a median split along the longest axis of the centres,
+    // recursively down to the length of a run.  The closest-hit update of the kernels that walk such tables does not
+    // depend on the order objects are met in (Closest<true> in rt_device.hip), and neither do the counters; but that
+    // update costs a little per candidate, so the new order is only taken when it
+    // shrinks the boxes' total area by a quarter (chapter_14's hexagon parts: by 40-50 %; 25 random objects in a cell
+    // of the generated scene: by 0-20 %, which was measured to buy nothing).
+    void spatial_order(std::vector<uint32_t> &list) {
+        auto finite = [&](uint32_t k) {
+            const Bounds &bb = in_parent[k];
+            return std::isfinite(bb.min.x) && std::isfinite(bb.min.y) && std::isfinite(bb.min.z) && std::isfinite(bb.max.x) &&
+                   std::isfinite(bb.max.y) && std::isfinite(bb.max.z);
+        };
+        std::vector<uint32_t> sorted = list;
+        const auto first_finite = std::stable_partition(sorted.begin(), sorted.end(), [&](uint32_t k) { return !finite(k); });
+        std::vector<uint32_t> bounded_in_order(first_finite, sorted.end());  // the reference's order, unbounded ones taken out
+        auto centre = [&](uint32_t k, int axis) {
+            const Bounds &bb = in_parent[k];
+            return axis == 0 ? bb.min.x + bb.max.x : axis == 1 ? bb.min.y + bb.max.y : bb.min.z + bb.max.z;
+        };
+        struct Split {
+            decltype(centre) &centre;
+            void run(std::vector<uint32_t>::iterator lo, std::vector<uint32_t>::iterator hi) const {
+                const size_t n = (size_t)(hi - lo);
+                if (n <= SKIP_RUN) {
+                    std::sort(lo, hi);  // inside a run: the reference's order
+                    return;
+                }
+                double cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (auto it = lo; it != hi; ++it)
+                    for (int a = 0; a < 3; ++a) {
+                        cmin[a] = std::fmin(cmin[a], centre(*it, a));
+                        cmax[a] = std::fmax(cmax[a], centre(*it, a));
+                    }
+                int axis = 0;
+                for (int a = 1; a < 3; ++a)
+                    if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+                const auto mid = lo + (std::ptrdiff_t)(n / 2);
+                std::nth_element(lo, mid, hi, [&](uint32_t x, uint32_t y) {
+                    const double cx = centre(x, axis), cy = centre(y, axis);
+                    return cx < cy || (cx == cy && x < y);
+                });
+                run(lo, mid);
+                run(mid, hi);
+            }
+        };
+        Split{centre}.run(first_finite, sorted.end());
+        if (sorted == list) return;
+        const std::vector<uint32_t> bounded_sorted(first_finite, sorted.end());
+        const double before = boxes_area(bounded_in_order, 0, bounded_in_order.size(), true);
+        const double after = boxes_area(bounded_sorted, 0, bounded_sorted.size(), true);
+        if (after < 0.75 * before) {
+            list.swap(sorted);
+            out.reordered = true;
+        }
     }
 
     // Pass 2: emits siblings list[a..b) in order, wrapping sub-ranges of long lists in range-skip nodes.
@@ -280,6 +361,7 @@ struct Builder {
 
         if (o.kind == RT_GROUP) {
             out.n_groups++;
+            if (kids[idx].size() > SKIP_MIN_LIST) spatial_order(kids[idx]);
             if (!emit_range(kids[idx], 0, kids[idx].size(), depth + 1, true)) return false;
             const Bounds &gb = own[idx];
             RtNode &n = out.nodes[ni];
@@ -315,10 +397,9 @@ struct Builder {
         RtNode &n = out.nodes[ni];
         n.a[0] = o.minimum;
         n.a[1] = o.maximum;
-        n.leaf = (int32_t)out.surfaces.size();
+        n.leaf = leaf_id[idx];
         n.skip = (int32_t)ni + 1;
-        out.surfaces.push_back(s);
-        out.n_leaves++;
+        out.surfaces[(size_t)leaf_id[idx]] = s;
         return true;
     }
 };
@@ -337,6 +418,7 @@ int flatten_world(const rt_world_desc &world, FlatScene &out, std::string &err) 
     b.in_parent.resize(world.n_objects);
     b.kids.resize(world.n_objects);
     b.cones.resize(world.n_objects);
+    b.leaf_id.assign(world.n_objects, -1);
     std::vector<uint32_t> top;
     uint32_t idx = 0;
     while (idx < world.n_objects) {
@@ -352,6 +434,8 @@ int flatten_world(const rt_world_desc &world, FlatScene &out, std::string &err) 
         err = buf;
         return RT_ERR_UNSUPPORTED;
     }
+    out.surfaces.resize(out.n_leaves);
+    if (top.size() > SKIP_MIN_LIST) b.spatial_order(top);
     if (!b.emit_range(top, 0, top.size(), 0, true)) return b.code;
     out.light.has_light = world.has_light ? 1 : 0;
     for (int i = 0; i < 3; ++i) {

@@ -17,6 +17,7 @@ struct FlatScene {
     uint32_t n_leaves = 0;
     uint32_t n_skip_nodes = 0;  // range-skip nodes added to the table (not objects of the world)
     uint32_t max_nesting = 0;  // deepest nesting level of any node (top-level objects are level 0)
+    bool reordered = false;    // a sibling list was emitted in spatial order instead of the reference's
 };
 
 // Returns RT_OK or an RT_ERR_* code with a message in err.

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--configs", default="c2,c3,c4,c5")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--size", default=None, help="WxH for every configuration instead of its own size")
     a = ap.parse_args()
     for name in a.configs.split(","):
         text = scene_text(name)
@@ -59,7 +60,7 @@ def main():
             err = float(np.abs(img - ref).max())
             status = (f"check {w}x{h}: max|d|={err:.1e} counters={'ok' if st.as_dict() == oc.as_dict() else 'DIFFER'} "
                       f"kernels={'agree' if np.array_equal(img, counted) else 'DISAGREE'}")
-        w, h = SIZES[name]
+        w, h = SIZES[name] if a.size is None else tuple(int(v) for v in a.size.split("x"))
         cam = sf.build_camera(w, h)
         img, st = scene.render(cam, stats=True)
         times = []

@@ -444,6 +444,59 @@ def test_cone_linear_shortcut_survives_range_skipping(gpu, rt, orc):
     _lone_rays_agree(orc, w.scene(), ow, rays)
 
 
+def test_ties_between_objects_in_reordered_lists(gpu, rt, orc):
+    """Long sibling lists are emitted in spatial order when that makes their range-skip boxes much smaller; the hit
+    among exactly equal t's must still be the reference's, the object listed first in the scene (world.rs:34 sorts
+    stably).  Pairs of unit spheres half a unit apart in y, hit by a ray halfway between them: the same t to the
+    last bit, from two different objects whose order in the file is random.  The pairs stand so close together along
+    x that the spatial order has to separate the upper spheres from the lower ones, which reverses about half the
+    pairs."""
+    import tomli
+
+    rng = np.random.default_rng(17)
+    n_pairs = 24
+    centres = [(0.05 * k, 0.0, 0.0) for k in range(n_pairs)] + [(0.05 * k, 0.5, 0.0) for k in range(n_pairs)]
+    order = rng.permutation(len(centres))
+    # A frame one pixel high: half_height = half_view / 64 and (0 + 0.5) * pixel_size = half_view / 64 are the same
+    # double, so every camera ray lies exactly in the plane y = 0.25 between the two spheres of each pair.
+    lines = ["[camera]", "width = 512", "height = 1", "fov = 20.0", "from = [0.575, 0.25, -20.0]", "to = [0.575, 0.25, 0.0]",
+             "up = [0.0, 1.0, 0.0]", "[light]", "position = [-10.0, 10.0, -10.0]", "intensity = [1.0, 1.0, 1.0]"]
+    for i in order:
+        c = centres[i]
+        lines += ["[[objects]]", 'type = "sphere"', "[objects.transform]", f"translate = [{c[0]}, {c[1]}, {c[2]}]",
+                  "[objects.material]", f"color = [{0.2 + 0.03 * (i % 24)}, {0.9 - 0.03 * (i % 24)}, {0.5 if i < 24 else 0.1}]",
+                  "reflectivity = 0.3"]
+    text = "\n".join(lines) + "\n"
+    sf = rt.SceneFile.from_str(text)
+    cam, world = sf.build_camera(), sf.build_world()
+    ocam, oworld = orc.scene_from_dict(tomli.loads(text))
+    scene = world.scene()
+    rays = np.array([[0.05 * k, 0.25, -5.0, 0.0, 0.0, 1.0] for k in range(n_pairs)])
+    t, obj = scene.intersect(rays)
+    lists = scene.intersect_all(rays)
+    first_of_pair_wins = 0
+    for k, ray in enumerate(rays):
+        want = oworld.intersect(orc.ray(ray[:3], ray[3:]))
+        assert want[0][0] == want[1][0] and want[0][1] != want[1][1], "the pair must tie exactly"
+        assert (t[k], obj[k]) == want[0], (k, (t[k], obj[k]), want[:2])
+        assert lists[k] == [(a, b) for a, b in want]
+        first_of_pair_wins += int(obj[k] == min(want[0][1], want[1][1]))
+    assert first_of_pair_wins == n_pairs
+    img, st = scene.render(cam, stats=True)
+    oc = orc.Counters()
+    ref = orc.render(ocam, oworld, threads=1, counters=oc)
+    tied = 0
+    for x in range(cam.hsize):
+        r = orc.ray_for_pixel(ocam, x, 0)
+        xs = oworld.intersect(r)
+        tied += int(len(xs) >= 2 and xs[0][0] == xs[1][0] and xs[0][1] != xs[1][1])
+    assert tied >= 100, "the frame is meant to consist of tied primary hits"
+    assert_frames_match(orc, img, ref)
+    counters_equal(st, oc)
+    plain, _ = scene.render(cam)
+    assert np.array_equal(plain, img)
+
+
 def test_degenerate_worlds(gpu, rt, orc):
     """Empty world, a childless group, no light source, and a flat list long enough to get range-skip nodes."""
     cam, ocam = rt.Camera(40, 30, 1.0), orc.camera(40, 30, 1.0)
