@@ -253,7 +253,7 @@ struct Builder {
     // recursively down to the length of a run.  The closest-hit update of the kernels that walk such tables does not
     // depend on the order objects are met in (Closest<true> in rt_device.hip), and neither do the counters; but that
     // update costs a little per candidate, so the new order is only taken when it
-    // shrinks the boxes' total area by a quarter (chapter_14's hexagon parts: by 40-50 %; 25 random objects in a cell
+    // shrinks the boxes' total area by a quarter (the twenty spheres of a chapter_14 group: by 40-50 %; 25 random objects in a cell
     // of the generated scene: by 0-20 %, which was measured to buy nothing).
     void spatial_order(std::vector<uint32_t> &list) {
         auto finite = [&](uint32_t k) {
