@@ -1453,15 +1453,31 @@ template <bool STATS>
 static void launch_render_nest(int nest, dim3 grid, unsigned block, hipStream_t stream, const DeviceScene &scene, const RtCameraDev &camera,
                                const RowMap &rows, int max_depth, double *rgb, unsigned long long *counters) {
     const size_t lds = (block / 64) * RAY_STACK_LDS_BYTES_PER_WAVE;
-    // The counting variant always breaks ties by leaf number (right for any table order); the plain one does so
-    // only when the host reordered a sibling list, because the comparison is paid per candidate.
-    const bool ties = STATS || scene.any_order != 0;
 #define RT_LAUNCH(N, T) render_kernel<STATS, N, T><<<grid, block, lds, stream>>>(scene, camera, rows, max_depth, rgb, counters)
-    switch (nest) {
-        case 0: RT_LAUNCH(0, false); break;
-        case 1: if (ties) RT_LAUNCH(1, true); else RT_LAUNCH(1, STATS); break;
-        case 2: if (ties) RT_LAUNCH(2, true); else RT_LAUNCH(2, STATS); break;
-        default: if (ties) RT_LAUNCH(RT_MAX_GROUP_NESTING, true); else RT_LAUNCH(RT_MAX_GROUP_NESTING, STATS); break;
+    if (nest == 0) {
+        RT_LAUNCH(0, false);
+        return;
+    }
+    // The counting variant always breaks ties by leaf number (right for any table order, and its speed does not
+    // matter); the plain one only when the host reordered a sibling list, because the comparison is paid per candidate.
+    if constexpr (STATS) {
+        switch (nest) {
+            case 1: RT_LAUNCH(1, true); break;
+            case 2: RT_LAUNCH(2, true); break;
+            default: RT_LAUNCH(RT_MAX_GROUP_NESTING, true); break;
+        }
+    } else if (scene.any_order != 0) {
+        switch (nest) {
+            case 1: RT_LAUNCH(1, true); break;
+            case 2: RT_LAUNCH(2, true); break;
+            default: RT_LAUNCH(RT_MAX_GROUP_NESTING, true); break;
+        }
+    } else {
+        switch (nest) {
+            case 1: RT_LAUNCH(1, false); break;
+            case 2: RT_LAUNCH(2, false); break;
+            default: RT_LAUNCH(RT_MAX_GROUP_NESTING, false); break;
+        }
     }
 #undef RT_LAUNCH
 }
