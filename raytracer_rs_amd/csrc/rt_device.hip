@@ -487,9 +487,16 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
     bool have_inv = false;
     int i = begin;
     while (i < end) {
-        const int tag = uniform(raw.b[8]), xform = uniform(raw.b[9]), leaf = uniform(raw.b[10]), skip = uniform(raw.b[11]);
+        // The control words move to registers of their own, so that nothing of the record is needed once the ray
+        // has been transformed and the next record can be loaded where this one lies.
+        int tag, xform, leaf, skip, a0lo, a0hi, a1lo, a1hi;
+        asm volatile("s_mov_b32 %0, %8\n\ts_mov_b32 %1, %9\n\ts_mov_b32 %2, %10\n\ts_mov_b32 %3, %11\n\t"
+                     "s_mov_b32 %4, %12\n\ts_mov_b32 %5, %13\n\ts_mov_b32 %6, %14\n\ts_mov_b32 %7, %15"
+                     : "=&s"(tag), "=&s"(xform), "=&s"(leaf), "=&s"(skip), "=&s"(a0lo), "=&s"(a0hi), "=&s"(a1lo), "=&s"(a1hi)
+                     : "s"(raw.b[8]), "s"(raw.b[9]), "s"(raw.b[10]), "s"(raw.b[11]), "s"(raw.b[12]), "s"(raw.b[13]),
+                       "s"(raw.b[14]), "s"(raw.b[15]));
         const int kind = tag & 0xff;
-        const double a0 = dwords_to_double(raw.b[12], raw.b[13]), a1 = dwords_to_double(raw.b[14], raw.b[15]);
+        const double a0 = dwords_to_double(a0lo, a0hi), a1 = dwords_to_double(a1lo, a1hi);
         // Everything that reads the first 96 bytes of the record happens before the next record is requested.
         V3 lo = o, ld = d;
         bool shortcut = false;  // a cone below this range-skip node takes the reference's linear shortcut for this ray
@@ -517,6 +524,7 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
         // The record to have ready next: the following one -- except after a range-skip node, which more often
         // than not sends the traversal to `skip` (the table has one spare record at its end).
         const int guess = (WIDE && kind == RT_SKIPBOX && !STATS && !B::every) ? skip : i + 1;
+        asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(ld.x), "+v"(ld.y), "+v"(ld.z));  // the transform is complete
         NodeRaw nraw = node_fetch<WIDE>(S.nodes + guess);
         int ni = i + 1;
         RT_NODE_VISIT(kind == RT_SKIPBOX ? 0 : kind == RT_GROUP ? 1 : 2);
