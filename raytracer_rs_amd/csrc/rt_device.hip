@@ -489,14 +489,17 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
     while (i < end) {
         // The control words move to registers of their own, so that nothing of the record is needed once the ray
         // has been transformed and the next record can be loaded where this one lies.
-        int tag, xform, leaf, skip, a0lo, a0hi, a1lo, a1hi;
-        asm volatile("s_mov_b32 %0, %8\n\ts_mov_b32 %1, %9\n\ts_mov_b32 %2, %10\n\ts_mov_b32 %3, %11\n\t"
-                     "s_mov_b32 %4, %12\n\ts_mov_b32 %5, %13\n\ts_mov_b32 %6, %14\n\ts_mov_b32 %7, %15"
-                     : "=&s"(tag), "=&s"(xform), "=&s"(leaf), "=&s"(skip), "=&s"(a0lo), "=&s"(a0hi), "=&s"(a1lo), "=&s"(a1hi)
-                     : "s"(raw.b[8]), "s"(raw.b[9]), "s"(raw.b[10]), "s"(raw.b[11]), "s"(raw.b[12]), "s"(raw.b[13]),
-                       "s"(raw.b[14]), "s"(raw.b[15]));
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        long long w0, w1, w2, w3;
+        asm volatile("s_mov_b64 %0, %4\n\ts_mov_b64 %1, %5\n\ts_mov_b64 %2, %6\n\ts_mov_b64 %3, %7"
+                     : "=&s"(w0), "=&s"(w1), "=&s"(w2), "=&s"(w3)
+                     : "s"(__builtin_bit_cast(long long, (i32x2)__builtin_shufflevector(raw.b, raw.b, 8, 9))),
+                       "s"(__builtin_bit_cast(long long, (i32x2)__builtin_shufflevector(raw.b, raw.b, 10, 11))),
+                       "s"(__builtin_bit_cast(long long, (i32x2)__builtin_shufflevector(raw.b, raw.b, 12, 13))),
+                       "s"(__builtin_bit_cast(long long, (i32x2)__builtin_shufflevector(raw.b, raw.b, 14, 15))));
+        const int tag = (int)w0, xform = (int)(w0 >> 32), leaf = (int)w1, skip = (int)(w1 >> 32);
+        const double a0 = __builtin_bit_cast(double, w2), a1 = __builtin_bit_cast(double, w3);
         const int kind = tag & 0xff;
-        const double a0 = dwords_to_double(a0lo, a0hi), a1 = dwords_to_double(a1lo, a1hi);
         // Everything that reads the first 96 bytes of the record happens before the next record is requested.
         V3 lo = o, ld = d;
         bool shortcut = false;  // a cone below this range-skip node takes the reference's linear shortcut for this ray
