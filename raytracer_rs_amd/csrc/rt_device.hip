@@ -497,7 +497,9 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
                        "s"(__builtin_bit_cast(long long, (i32x2)__builtin_shufflevector(raw.b, raw.b, 10, 11))),
                        "s"(__builtin_bit_cast(long long, (i32x2)__builtin_shufflevector(raw.b, raw.b, 12, 13))),
                        "s"(__builtin_bit_cast(long long, (i32x2)__builtin_shufflevector(raw.b, raw.b, 14, 15))));
-        const int tag = (int)w0, xform = (int)(w0 >> 32), leaf = (int)w1, skip = (int)(w1 >> 32);
+        // (the optimiser takes what an asm statement returns for possibly divergent; these are wave-uniform)
+        const int tag = uniform((int)w0), leaf = uniform((int)w1), skip = uniform((int)(w1 >> 32));
+        const int xform = uniform(raw.b[9]);  // only read before the next record is requested
         const double a0 = __builtin_bit_cast(double, w2), a1 = __builtin_bit_cast(double, w3);
         const int kind = tag & 0xff;
         // Everything that reads the first 96 bytes of the record happens before the next record is requested.
