@@ -98,8 +98,9 @@ def cpu_baseline(scene_path: str, width: int, height: int, seconds_target: float
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=25,
+                    help="untimed frames first; the GPU takes about 20 frames of this size to reach its steady clocks")
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "scenes", "chapter_11.toml"))
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -199,8 +200,8 @@ def main() -> None:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     # the render kernel's own duration (and the ordering pass before it): the last launches of the timed region
-    # (the handle keeps the events of eight)
-    times = [scene.render_times(back) for back in range(min(args.steps, 8))]
+    # (the handle keeps the events of 32)
+    times = [scene.render_times(back) for back in range(min(args.steps, 32))]
     ordering_ms = sum(t[0] for t in times) / max(1, len(times))
     kernel_ms = sum(t[1] for t in times) / max(1, len(times))
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)

@@ -174,7 +174,7 @@ int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const 
                      double *rgb_device, rt_stats *stats);
 
 /* Measurement aid, no counterpart in the reference: GPU time of a launch made with RT_RENDER_TIMED, `back` launches
- * ago (0 = the latest; the handle remembers eight): the tile-ordering pass and the render kernel, in milliseconds.
+ * ago (0 = the latest; the handle remembers 32): the tile-ordering pass and the render kernel, in milliseconds.
  * The caller must have synchronised the launch's stream first (RT_ERR_HIP otherwise). */
 int rt_scene_render_times(const rt_scene *scene, uint32_t back, double *ordering_ms, double *render_ms);
 

@@ -27,7 +27,7 @@ struct rt_scene {
     uint32_t *d_tiles = nullptr;  // tile-ordering scratch of launch_render, grown on demand
     size_t tiles_cap = 0;         // in 32-bit words
     bool uneven = false;          // tiles differ in cost by more than a shadow ray: ordering them pays
-    hipEvent_t marks[8][3] = {};  // event triples of the launches made with RT_RENDER_TIMED, used round-robin
+    hipEvent_t marks[32][3] = {};  // event triples of the launches made with RT_RENDER_TIMED, used round-robin
     uint32_t timed_launches = 0;
     rt::DeviceScene dev;
     std::vector<int32_t> object_to_leaf;
@@ -281,7 +281,7 @@ int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const 
     hipEvent_t *marks = nullptr;
     if (opts && (opts->flags & RT_RENDER_TIMED)) {
         rt_scene *mut = const_cast<rt_scene *>(scene);  // one render at a time per handle
-        marks = mut->marks[mut->timed_launches % 8];
+        marks = mut->marks[mut->timed_launches % 32];
         for (int k = 0; k < 3; ++k)
             if (!marks[k]) HIP_TRY(hipEventCreate(&marks[k]));
         mut->timed_launches++;
@@ -298,9 +298,9 @@ int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const 
 
 int rt_scene_render_times(const rt_scene *scene, uint32_t back, double *ordering_ms, double *render_ms) {
     if (!scene || !ordering_ms || !render_ms) return set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (back >= 8 || back >= scene->timed_launches)
+    if (back >= 32 || back >= scene->timed_launches)
         return set_error(RT_ERR_INVALID_ARGUMENT, "no launch with RT_RENDER_TIMED that far back");
-    const hipEvent_t *marks = scene->marks[(scene->timed_launches - 1 - back) % 8];
+    const hipEvent_t *marks = scene->marks[(scene->timed_launches - 1 - back) % 32];
     float a = 0.f, b = 0.f;
     HIP_TRY(hipEventElapsedTime(&a, marks[0], marks[1]));
     HIP_TRY(hipEventElapsedTime(&b, marks[1], marks[2]));

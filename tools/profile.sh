@@ -9,7 +9,7 @@ OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 EXTRA=("$@")
-STEPS=(--steps 20 --warmup 3)
+STEPS=(--steps 50 --warmup 25)
 
 run() { # name, timeout, rocprof args...
     local name=$1 to=$2

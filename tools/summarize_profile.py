@@ -22,7 +22,7 @@ def main() -> None:
     os.makedirs(dst, exist_ok=True)
     lines = [f"# rocprofv3 summary `{tag}`", "",
              "Command per pass: `rocprofv3 <pass args> --output-format csv -- python3 bench.py --no-cpu-baseline "
-             "--steps K --warmup W` (tools/profile.sh); kernel-trace pass K=20, counter passes K=3.", ""]
+             "--steps K --warmup W` (tools/profile.sh); kernel-trace pass K=50 W=25 (bench defaults), counter passes K=3 W=1.", ""]
 
     stats = os.path.join(src, "trace_kernel_stats.csv")
     shutil.copyfile(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
@@ -41,6 +41,14 @@ def main() -> None:
     lines += ["", f"bench.py in the same run: value {bench['value']} {bench['unit']}, ms_per_step {bench['ms_per_step']}, "
                   f"roofline.kernel_ms {bench['roofline']['kernel_ms']} (rocprof average {avg_ms:.4f} ms).", ""]
 
+    with open(os.path.join(src, "trace_kernel_trace.csv")) as f:
+        durations = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(f) if needle in r["Kernel_Name"]]
+    n_avg = int(bench["roofline"].get("launches_averaged", 0))
+    if n_avg and len(durations) >= n_avg:
+        tail = durations[-n_avg:]
+        lines += [f"The kernel trace of the {n_avg} launches `roofline.kernel_ms` averages (the last ones of the timed region): "
+                  f"mean {sum(tail) / len(tail):.4f} ms, min {min(tail):.4f}, max {max(tail):.4f}; the first launches of the run are slower "
+                  f"(the first one {durations[0]:.4f} ms): the GPU takes some twenty frames to reach its steady clocks.", ""]
     with open(os.path.join(src, "trace_kernel_trace.csv")) as f:
         for row in csv.DictReader(f):
             if needle in row["Kernel_Name"]:
