@@ -183,6 +183,20 @@ def main() -> None:
     rays_frame = total_counts["rays"]
     my_flops = algorithmic_flops(counts)
 
+    # The GPU takes ~40 ms of continuous work to reach its steady clocks (the first frames of a run are 15 % slower):
+    # on one GPU, whatever --warmup says, frames are rendered for a tenth of a second before anything is timed.  (With
+    # several ranks the warm-up is --warmup alone: the two-ranks-on-one-GPU gloo rehearsal of this script hangs in its
+    # first gather when anything is rendered before it, for a reason not found, and the flow it cannot rehearse is not
+    # the flow to send to a multi-GPU node.)
+    if world_size == 1:
+        t_pre = time.perf_counter()
+        k_pre = 0
+        while time.perf_counter() - t_pre < 0.1:
+            render_mine(k_pre)
+            k_pre += 1
+            if k_pre % 8 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
     for k in range(args.warmup):
         step(k)
     bg.finish()
