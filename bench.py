@@ -184,10 +184,8 @@ def main() -> None:
     my_flops = algorithmic_flops(counts)
 
     # The GPU takes ~40 ms of continuous work to reach its steady clocks (the first frames of a run are 15 % slower):
-    # on one GPU, whatever --warmup says, frames are rendered for a tenth of a second before anything is timed.  (With
-    # several ranks the warm-up is --warmup alone: the two-ranks-on-one-GPU gloo rehearsal of this script hangs in its
-    # first gather when anything is rendered before it, for a reason not found, and the flow it cannot rehearse is not
-    # the flow to send to a multi-GPU node.)
+    # whatever --warmup says, frames are rendered for a tenth of a second before anything is timed.  On one GPU that
+    # happens here; with several ranks after the --warmup steps, as whole steps.
     if world_size == 1:
         t_pre = time.perf_counter()
         k_pre = 0
@@ -199,6 +197,23 @@ def main() -> None:
         torch.cuda.synchronize()
     for k in range(args.warmup):
         step(k)
+    if world_size > 1 and backend == "nccl":
+        # the same warm-up for several ranks, as whole steps (render and gather, exactly what the timed loop does);
+        # the ranks agree on when a tenth of a second has passed, so that all of them stop after the same step.
+        # (Not in the gloo rehearsal: there torch's gloo gather of device tensors stops returning after a handful
+        # of calls -- tools/gloo_gather_probe.py shows it without any of this code -- so a rehearsal is kept short.)
+        t_pre = time.perf_counter()
+        k = args.warmup
+        while True:
+            for _ in range(16):
+                step(k)
+                k += 1
+            bg.finish()
+            torch.cuda.synchronize()
+            spent = torch.tensor([time.perf_counter() - t_pre], dtype=torch.float64, device=dev)
+            dist.all_reduce(spent, op=dist.ReduceOp.MAX)
+            if spent.item() >= 0.1:
+                break
     bg.finish()
     if world_size > 1:
         dist.barrier()
