@@ -118,6 +118,9 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    # RT_BENCH_FORCE_DIST=1: run the several-ranks path (process group, band buffers, gather on its own stream) even
+    # with one rank -- the way to exercise that path with the nccl backend on a box that has one GPU
+    multi = world_size > 1 or bool(os.environ.get("RT_BENCH_FORCE_DIST"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
     # Rehearsal on a box with fewer GPUs than ranks (RT_BENCH_BACKEND=gloo): ranks share devices and the gather goes
@@ -126,7 +129,7 @@ def main() -> None:
     device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
-    if world_size > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -140,17 +143,18 @@ def main() -> None:
     W, H = cam.hsize, cam.vsize
     # device buffers: my bands (padded to equal size so the gather is uniform) and, on rank 0, the frame
     u8 = args.frame == "u8"
-    bg = BandGather(W, H, rank, world_size, dev, BAND_ROWS, dtype=torch.uint8 if u8 else torch.float64)
+    bg = BandGather(W, H, rank, world_size, dev, BAND_ROWS, dtype=torch.uint8 if u8 else torch.float64,
+                    collective_even_alone=multi)
     stream = torch.cuda.current_stream().cuda_stream
     def render_mine(k: int = 0, stats: bool = False, timed: bool = False):
         """Frame k: this rank's bands, rendered (and quantised) into the buffer the gather of frame k reads.
         `timed`: the library records HIP events on the launch's stream before the tile-ordering pass, between it and
         the render kernel and after the render kernel (no synchronisation); read back after the timed region."""
-        target = bg.frame if world_size == 1 else bg.buffer(k)
-        if world_size > 1:
+        target = bg.frame if not multi else bg.buffer(k)
+        if multi:
             bg.begin_render(k)
         # with 8-bit collection the render kernel quantises its own output (RT_RENDER_QUANTIZED)
-        if world_size == 1:
+        if not multi:
             st = scene.render_device(cam, target.data_ptr(), None, 0, stream, stats, timed, u8)
         else:
             st = scene.render_device_bands(cam, target.data_ptr(), BAND_ROWS, rank, world_size, 0, stream, stats, timed, u8)
@@ -158,7 +162,7 @@ def main() -> None:
 
     def step(k: int):
         render_mine(k)
-        if world_size > 1:
+        if multi:
             bg.gather(k)
 
     # rays of the frame, counted once by the counting kernel (untimed)
@@ -169,7 +173,7 @@ def main() -> None:
         v = counts[k]
         flat.extend(v if isinstance(v, list) else [v])
     tot = torch.tensor(flat, dtype=torch.float64, device=dev)
-    if world_size > 1:
+    if multi:
         dist.all_reduce(tot)
     tot = [int(v) for v in tot.tolist()]
     total_counts, i = {}, 0
@@ -186,7 +190,7 @@ def main() -> None:
     # The GPU takes ~40 ms of continuous work to reach its steady clocks (the first frames of a run are 15 % slower):
     # whatever --warmup says, frames are rendered for a tenth of a second before anything is timed.  On one GPU that
     # happens here; with several ranks after the --warmup steps, as whole steps.
-    if world_size == 1:
+    if not multi:
         t_pre = time.perf_counter()
         k_pre = 0
         while time.perf_counter() - t_pre < 0.1:
@@ -197,7 +201,7 @@ def main() -> None:
         torch.cuda.synchronize()
     for k in range(args.warmup):
         step(k)
-    if world_size > 1 and backend == "nccl":
+    if multi and backend == "nccl":
         # the same warm-up for several ranks, as whole steps (render and gather, exactly what the timed loop does);
         # the ranks agree on when a tenth of a second has passed, so that all of them stop after the same step.
         # (Not in the gloo rehearsal: there torch's gloo gather of device tensors stops returning after a handful
@@ -215,16 +219,16 @@ def main() -> None:
             if spent.item() >= 0.1:
                 break
     bg.finish()
-    if world_size > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         render_mine(k, timed=True)
-        if world_size > 1:
+        if multi:
             bg.gather(k)  # on its own stream: overlaps the rendering of frame k+1
     bg.finish()
-    if world_size > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -234,7 +238,7 @@ def main() -> None:
     ordering_ms = sum(t[0] for t in times) / max(1, len(times))
     kernel_ms = sum(t[1] for t in times) / max(1, len(times))
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-    if world_size > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms_max = t.tolist()
 
@@ -295,7 +299,7 @@ def main() -> None:
         elif world_size == 1:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world_size > 1:
+    if multi:
         dist.destroy_process_group()
 
 

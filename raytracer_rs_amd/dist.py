@@ -53,23 +53,26 @@ class BandGather:
 
     def __init__(self, width: int, height: int, rank: int, world_size: int, device: torch.device,
                  band_rows: int = DEFAULT_BAND_ROWS, channels: int = 3, dtype: torch.dtype = torch.float64,
-                 depth: int = 2):
+                 depth: int = 2, collective_even_alone: bool = False):
         self.width, self.height, self.rank, self.world_size = width, height, rank, world_size
         self.band_rows, self.channels = band_rows, channels
         self.band_vals = band_rows * width * channels
         self.n_bands = n_bands(height, band_rows)
         self.slots = bands_per_rank(world_size, height, band_rows)
-        self.depth = max(1, depth) if world_size > 1 else 1
+        # collective_even_alone: a process group of ONE rank still goes through the send buffers, the side stream and
+        # the gather (the multi-rank path exercised end to end on a box with a single GPU)
+        self.collective = world_size > 1 or collective_even_alone
+        self.depth = max(1, depth) if self.collective else 1
         self.send = [torch.zeros(self.slots, self.band_vals, dtype=dtype, device=device) for _ in range(self.depth)]
         self.mine = self.send[0]
         self.frame: Optional[torch.Tensor] = None
         self._recv: Optional[List[torch.Tensor]] = None
         if rank == 0:
             self.frame = torch.zeros(self.n_bands, self.band_vals, dtype=dtype, device=device)
-            if world_size > 1:
+            if self.collective:
                 self._recv = [torch.empty_like(self.mine) for _ in range(world_size)]
         self._comm = None
-        if device.type == "cuda" and world_size > 1:
+        if device.type == "cuda" and self.collective:
             self._comm = torch.cuda.Stream(device=device)
             self._rendered = [torch.cuda.Event() for _ in range(self.depth)]
             self._gathered = [torch.cuda.Event() for _ in range(self.depth)]
@@ -87,7 +90,7 @@ class BandGather:
         """Collects every rank's bands of frame k on rank 0 and places them in the frame.  Returns the frame on
         rank 0 (on a GPU: once the work queued here has run; see finish())."""
         src = self.buffer(k)
-        if self.world_size == 1:
+        if not self.collective:
             self.frame[: self.slots].copy_(src)
             return self.frame
         if self._comm is None:
