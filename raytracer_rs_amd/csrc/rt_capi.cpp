@@ -168,6 +168,8 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     std::string err;
     int rc = rt::flatten_world(*world, sc->flat, err);
     if (rc != RT_OK) return set_error(rc, err);
+    if ((sc->flat.nodes.size() + 1) * sizeof(RtNode) >= (1ull << 32))  // the traversal addresses records by 32-bit byte offsets
+        return set_error(RT_ERR_UNSUPPORTED, "the world has too many objects for one node table (4 GB of records)");
     sc->object_to_leaf.assign(world->n_objects, -1);
     for (size_t leaf = 0; leaf < sc->flat.surfaces.size(); ++leaf)
         sc->object_to_leaf[(size_t)sc->flat.surfaces[leaf].object] = (int32_t)leaf;

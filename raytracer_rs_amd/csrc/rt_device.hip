@@ -414,8 +414,9 @@ struct NodeRaw {
 static_assert(sizeof(RtNode) == 160 && offsetof(RtNode, tag) == 96 && offsetof(RtNode, a) == 112, "RtNode layout moved");
 
 template <bool WIDE>
-__device__ __forceinline__ NodeRaw node_fetch(NodeP n) {
-    const char RT_CONSTANT_AS *p = (const char RT_CONSTANT_AS *)n;
+__device__ __forceinline__ NodeRaw node_fetch(NodeP table, int index) {
+    // a 32-bit byte offset (tables are far below 4 GB): one scalar multiply instead of a 64-bit one
+    const char RT_CONSTANT_AS *p = (const char RT_CONSTANT_AS *)table + (unsigned)index * (unsigned)sizeof(RtNode);
     NodeRaw r;
     r.a = *(const volatile i32x16 RT_CONSTANT_AS *)(p);
     r.b = *(const volatile i32x16 RT_CONSTANT_AS *)(p + 64);
@@ -478,7 +479,7 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
                                             B &best, Ctr<STATS> &ctr) {
     constexpr bool WIDE = NEST > 0;
     if (begin >= end) return;
-    NodeRaw raw = node_fetch<WIDE>(S.nodes + begin);
+    NodeRaw raw = node_fetch<WIDE>(S.nodes, begin);
     // Consume one word of the first record here, so that its arrival is awaited before the loop and not at the top
     // of every iteration (where the wait would also cover the request for the following record).
     asm volatile("" ::"s"(raw.b[8]));
@@ -530,7 +531,7 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
         // than not sends the traversal to `skip` (the table has one spare record at its end).
         const int guess = (WIDE && kind == RT_SKIPBOX && !STATS && !B::every) ? skip : i + 1;
         asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(ld.x), "+v"(ld.y), "+v"(ld.z));  // the transform is complete
-        NodeRaw nraw = node_fetch<WIDE>(S.nodes + guess);
+        NodeRaw nraw = node_fetch<WIDE>(S.nodes, guess);
         int ni = i + 1;
         RT_NODE_VISIT(kind == RT_SKIPBOX ? 0 : kind == RT_GROUP ? 1 : 2);
         if (WIDE && kind == RT_SKIPBOX) {
@@ -595,7 +596,7 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
             ni = skip;
         }
         if constexpr (NEST > 0) {
-            if (ni != guess) nraw = node_fetch<WIDE>(S.nodes + ni);  // guessed wrong: fetch the record wanted
+            if (ni != guess) nraw = node_fetch<WIDE>(S.nodes, ni);  // guessed wrong: fetch the record wanted
         }
         // One definition of the closest hit per iteration: without it the optimiser carries two copies of (t, leaf)
         // round the loop -- the one the tests read and the one the caller gets -- and moves both at every join.
