@@ -734,3 +734,46 @@ def test_full_8k_generated_hierarchy(gpu, rt, orc):
     assert (cam.hsize, cam.vsize) == (7680, 4320)
     ocam, oworld = orc.scene_from_dict(tomli.loads(text))
     _full_size_checks(orc, world.scene(), cam, ocam, oworld, n_sample_bands=8)
+
+
+def test_frame_beyond_four_gigabytes(gpu, rt, orc):
+    """Offsets into the frame that need more than 32 bits: chapter_7_and_8 at 16384x12288 is 4.8 GB of f64 (4.2 million
+    tiles).  Rendered into device memory; the rows at the top, either side of the 4 GiB mark and at the bottom are
+    compared with the oracle and with the same rows rendered alone, and nothing is written past the end."""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    W, H = 16384, 12288
+    cam, world, ocam, oworld = load_both(rt, orc, "chapter_7_and_8", W, H)
+    scene = world.scene()
+    row_bytes = W * 3 * 8
+    total = H * row_bytes
+    assert total > 1 << 32
+    mark = (1 << 32) // row_bytes  # the row the 4 GiB offset falls in
+    guard = 4096
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), total + guard) == 0
+    try:
+        assert hip.hipMemset(ctypes.c_void_p(buf.value + total), 0x5A, guard) == 0
+        scene.render_device(cam, buf.value)
+        assert hip.hipDeviceSynchronize() == 0
+        tail = np.zeros(guard, dtype=np.uint8)
+        assert hip.hipMemcpy(tail.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(buf.value + total), guard, 2) == 0
+        assert (tail == 0x5A).all(), "wrote past the end of the frame"
+        for y0 in (0, mark - 2, mark + 1, H // 2, H - 4):
+            got = np.zeros((4, W, 3))
+            assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(buf.value + y0 * row_bytes), got.nbytes, 2) == 0
+            ref = orc.render(ocam, oworld, threads=16, rows=(y0, y0 + 4))
+            assert_frames_match(orc, got, ref[y0:y0 + 4])
+            del ref
+            scene.render_device(cam, buf.value, rows=(y0, y0 + 4))  # packed at the start of the buffer
+            assert hip.hipDeviceSynchronize() == 0
+            alone = np.zeros((4, W, 3))
+            assert hip.hipMemcpy(alone.ctypes.data_as(ctypes.c_void_p), buf, alone.nbytes, 2) == 0
+            assert np.array_equal(alone, got)
+    finally:
+        hip.hipFree(buf)
