@@ -30,14 +30,14 @@
 #ifdef RT_TIMING
 // Developer build (-DRT_TIMING): per-wave shader-clock totals of the phases of radiance() (tools/timing.py reads them).
 #define RT_TIMING_WAVES (1 << 20)
-__device__ unsigned long long g_rt_timing[RT_TIMING_WAVES][6];  // per wave: trace | shade<<32, real-time begin, iterations | lanes<<32, lifetime | real-time lifetime<<40, skip | group<<32 node visits, leaf visits
+__device__ unsigned long long g_rt_timing[RT_TIMING_WAVES][6];  // per wave: trace | shade<<32, real-time begin, iterations | lanes<<32, lifetime | real-time lifetime<<40, skip | group<<32 node visits, leaf visits | records fetched twice<<32
 extern "C" int rt_debug_timing(unsigned long long *out, unsigned n_waves) {
     if (n_waves > RT_TIMING_WAVES) n_waves = RT_TIMING_WAVES;
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rt_timing), (size_t)n_waves * 6 * sizeof(unsigned long long));
     return e == hipSuccess ? 0 : -4;
 }
 #define RT_TIC(var) const long long var = clock64()
-__shared__ unsigned rt_wave_nodes[4];  // node records this wave visited: skip, group, leaf (one wave per workgroup)
+__shared__ unsigned rt_wave_nodes[4];  // node records this wave visited: skip, group, leaf; wrong guesses of the next record (one wave per workgroup)
 #define RT_NODE_VISIT(k) if ((threadIdx.x & 63) == 0) atomicAdd(&rt_wave_nodes[k], 1u)
 #else
 #define RT_TIC(var)
@@ -596,7 +596,10 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
             ni = skip;
         }
         if constexpr (NEST > 0) {
-            if (ni != guess) nraw = node_fetch<WIDE>(S.nodes, ni);  // guessed wrong: fetch the record wanted
+            if (ni != guess) {
+                nraw = node_fetch<WIDE>(S.nodes, ni);  // guessed wrong: fetch the record wanted
+                RT_NODE_VISIT(3);
+            }
         }
         // One definition of the closest hit per iteration: without it the optimiser carries two copies of (t, leaf)
         // round the loop -- the one the tests read and the one the caller gets -- and moves both at every join.
@@ -974,7 +977,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
             g_rt_timing[wv][2] = (unsigned long long)tm_iters | ((unsigned long long)tm_lanes << 32);
             g_rt_timing[wv][3] = (unsigned long long)(clock64() - tm_begin) | ((unsigned long long)(wall_clock64() - tm_rbegin) << 40);
             g_rt_timing[wv][4] = (unsigned long long)rt_wave_nodes[0] | ((unsigned long long)rt_wave_nodes[1] << 32);
-            g_rt_timing[wv][5] = (unsigned long long)rt_wave_nodes[2];
+            g_rt_timing[wv][5] = (unsigned long long)rt_wave_nodes[2] | ((unsigned long long)rt_wave_nodes[3] << 32);
         }
     }
 #endif

@@ -58,10 +58,11 @@ def main():
           f"active lanes/iteration {lanes.sum() / iters.sum():.1f}")
     print(f"per wave: lifetime {life.mean():.0f} clk (max {life.max():.0f}), trace {trace.mean():.0f} clk, shade {shade.mean():.0f} clk")
     print(f"per iteration: trace {trace.sum() / iters.sum():.0f} clk, shade {shade.sum() / iters.sum():.0f} clk")
-    skipn, groupn, leafn = (buf[:, 4] & m32).astype(float), (buf[:, 4] >> np.uint64(32)).astype(float), buf[:, 5].astype(float)
+    skipn, groupn, leafn = (buf[:, 4] & m32).astype(float), (buf[:, 4] >> np.uint64(32)).astype(float), (buf[:, 5] & m32).astype(float)
+    again = (buf[:, 5] >> np.uint64(32)).astype(float)
     nodes = skipn + groupn + leafn
     print(f"node records per traversal (wave level): skip {skipn.sum() / iters.sum():.1f}, group {groupn.sum() / iters.sum():.1f}, "
-          f"leaf {leafn.sum() / iters.sum():.1f}; trace clocks per node {trace.sum() / max(1.0, nodes.sum()):.0f}")
+          f"leaf {leafn.sum() / iters.sum():.1f}, next record guessed wrong {again.sum() / iters.sum():.1f}; trace clocks per node {trace.sum() / max(1.0, nodes.sum()):.0f}")
     worst = int(np.argmax(life))
     print(f"longest wave: {iters[worst]:.0f} iterations, {lanes[worst] / iters[worst]:.1f} active lanes, {nodes[worst] / iters[worst]:.0f} nodes "
           f"per traversal, {trace[worst] / max(1.0, nodes[worst]):.0f} trace clocks per node, lifetime {life[worst] / 1e6:.1f} Mclk")
