@@ -476,10 +476,12 @@ __device__ __forceinline__ bool box_may_hit(const double (&bb)[6], V3 o, V3 inv,
 // record into the registers the matrix occupied, then run the shape or bounds test while that request is in flight.
 template <int D, int NEST, bool STATS, class B>
 __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end, V3 o, V3 d, bool active, double far,
-                                            B &best, Ctr<STATS> &ctr) {
+                                            B &best, Ctr<STATS> &ctr, const NodeRaw *first = nullptr) {
     constexpr bool WIDE = NEST > 0;
     if (begin >= end) return;
-    NodeRaw raw = node_fetch<WIDE>(S.nodes, begin);
+    // `first`: the record at `begin` when the caller has requested it already (a group's first child is the record
+    // after the group's own)
+    NodeRaw raw = first ? *first : node_fetch<WIDE>(S.nodes, begin);
     // Consume one word of the first record here, so that its arrival is awaited before the loop and not at the top
     // of every iteration (where the wait would also cover the request for the following record).
     asm volatile("" ::"s"(raw.b[8]));
@@ -554,7 +556,7 @@ __device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end,
                     ctr.add(C_AABB);
                 }
                 if constexpr (!STATS) ctr.visits += inside ? 4u : 0u;
-                if (__ballot(inside) != 0ull) trace_range<D + 1, NEST, STATS, B>(S, i + 1, skip, lo, ld, inside, far, best, ctr);
+                if (__ballot(inside) != 0ull) trace_range<D + 1, NEST, STATS, B>(S, i + 1, skip, lo, ld, inside, far, best, ctr, &nraw);
                 ni = skip;
             }
         } else if (kind != RT_GROUP) {
