@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 enum {
     RT_OK = 0,
@@ -172,6 +172,22 @@ int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_rend
  * collect_stats is set. */
 int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
                      double *rgb_device, rt_stats *stats);
+
+/* rt_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  No counterpart in the reference.  Same arguments and the same pixels as rt_render_device,
+ * but the call makes no hipMalloc / hipFree / event or stream creation: the tile-ordering scratch its kernels use (the
+ * one buffer rt_render_device allocates on demand) lives in a static device array of RT_NOALLOC_SCRATCH_BYTES that
+ * every GPU holds from the library's first use on it until the process ends; its address is looked up when a scene is
+ * created on that GPU.  Limits: the rows rendered by one call may cover at most RT_NOALLOC_MAX_TILES 8x8-pixel tiles
+ * (ceil(hsize/8) * ceil(rows/8); 7680x4320 is 518 400) -- more fails with RT_ERR_CAPACITY; collect_stats and
+ * RT_RENDER_TIMED are refused (RT_ERR_INVALID_ARGUMENT: they need a host synchronisation resp. event creation).
+ * All calls on one GPU -- through any scene handle -- share that GPU's array: calls that overlap in time on one GPU
+ * race on the tile order (the caller serialises them, e.g. by using one stream); the array keeps the last call's
+ * contents and every call rewrites what it reads. */
+#define RT_NOALLOC_MAX_TILES 524288u
+#define RT_NOALLOC_SCRATCH_BYTES ((256u + 3u * RT_NOALLOC_MAX_TILES) * 4u)
+int rt_render_device_noalloc(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
+                             double *rgb_device);
 
 /* Measurement aid, no counterpart in the reference: GPU time of a launch made with RT_RENDER_TIMED, `back` launches
  * ago (0 = the latest; the handle remembers 32): the tile-ordering pass and the render kernel, in milliseconds.

@@ -23,6 +23,7 @@ DEFAULT_DEPTH = 5
 RENDER_TIMED = 1
 RENDER_QUANTIZED = 2
 MAX_DEPTH = 8
+NOALLOC_MAX_TILES = 524288
 
 
 class RtError(RuntimeError):
@@ -107,6 +108,7 @@ SIGNATURES = {
     "rt_scene_get_info": (C.c_int, [C.c_void_p, _P(SceneInfo)]),
     "rt_render": (C.c_int, [C.c_void_p, _P(CameraDesc), _P(RenderOpts), _P(C.c_double), _P(Stats)]),
     "rt_render_device": (C.c_int, [C.c_void_p, _P(CameraDesc), _P(RenderOpts), C.c_void_p, _P(Stats)]),
+    "rt_render_device_noalloc": (C.c_int, [C.c_void_p, _P(CameraDesc), _P(RenderOpts), C.c_void_p]),
     "rt_scene_render_times": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_double), _P(C.c_double)]),
     "rt_color_at": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_int32, _P(C.c_double), _P(Stats)]),
     "rt_intersect": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, _P(C.c_double), _P(C.c_int32)]),

@@ -356,6 +356,22 @@ class Scene:
         L.check(L.lib().rt_render_device(self._h, C.byref(cd), C.byref(opts), C.c_void_p(device_ptr), C.byref(st)))
         return st if stats else None
 
+    def render_device_noalloc(self, camera: "Camera", device_ptr: int, rows: Optional[Tuple[int, int]] = None,
+                              bands: Optional[Tuple[int, int, int]] = None, max_depth: int = 0, stream: int = 0,
+                              quantized: bool = False) -> None:
+        """rt_render_device_noalloc: rt_render_device without any allocation (its tile-ordering scratch is a static
+        device array); at most NOALLOC_MAX_TILES 8x8-pixel tiles per call."""
+        cd = camera._desc()
+        opts = L.RenderOpts()
+        if rows is not None:
+            opts.row_begin, opts.row_end = rows
+        if bands is not None:
+            opts.band_rows, opts.band_first, opts.band_step = bands
+        opts.max_depth = max_depth
+        opts.stream = C.c_void_p(stream)
+        opts.flags = L.RENDER_QUANTIZED if quantized else 0
+        L.check(L.lib().rt_render_device_noalloc(self._h, C.byref(cd), C.byref(opts), C.c_void_p(device_ptr)))
+
     def color_at(self, rays: np.ndarray, remaining: int = L.DEFAULT_DEPTH, stats: bool = False):
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
         out = np.zeros((rays.shape[0], 3), dtype=np.float64)

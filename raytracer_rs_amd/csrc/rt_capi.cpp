@@ -183,6 +183,9 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     sc->device = device;
     DeviceGuard guard(device);
     if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+    // Set-up for rt_render_device_noalloc: the address of this GPU's copy of the static scratch array, looked up once
+    // per device while that device is current.  A failure only disables that entry point (it reports it).
+    (void)rt::static_render_scratch_resolve(device);
 
     size_t nb = sc->flat.nodes.size() * sizeof(RtNode), sb = sc->flat.surfaces.size() * sizeof(RtSurface);
     // one inert record past the end: the traversal prefetches node i+1 while it works on node i
@@ -244,10 +247,13 @@ int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out) {
 
 // Tile-ordering scratch of the handle, grown on demand (the handle is used by one render at a time).  RT_TILE_ORDER=0
 // in the environment turns the ordering off (developer A/B switch).
-static hipError_t tile_scratch(const rt_scene *scene_c, const rt_camera_desc *camera, const rt::RowMap &rows, uint32_t **out) {
+static bool tile_order_enabled() {
     static const bool enabled = [] { const char *e = getenv("RT_TILE_ORDER"); return !(e && e[0] == '0'); }();
+    return enabled;
+}
+static hipError_t tile_scratch(const rt_scene *scene_c, const rt_camera_desc *camera, const rt::RowMap &rows, uint32_t **out) {
     *out = nullptr;
-    if (!enabled || rows.n_rows == 0 || !scene_c->uneven) return hipSuccess;
+    if (!tile_order_enabled() || rows.n_rows == 0 || !scene_c->uneven) return hipSuccess;
     rt_scene *scene = const_cast<rt_scene *>(scene_c);
     const size_t need = rt::render_scratch_words(camera->hsize, rows.n_rows);
     if (need > scene->tiles_cap) {
@@ -295,6 +301,39 @@ int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const 
         HIP_TRY(hipStreamSynchronize(stream));
         stats_from_counters(c, stats);
     }
+    return RT_OK;
+}
+
+int rt_render_device_noalloc(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
+                             double *rgb_device) {
+    rt::RowMap rows;
+    int depth;
+    RtCameraDev cam;
+    int rc = render_rows(scene, camera, opts, rows, depth, cam);
+    if (rc != RT_OK) return rc;
+    if (!rgb_device && rows.n_rows) return set_error(RT_ERR_INVALID_ARGUMENT, "rgb_device must not be NULL");
+    if (opts && opts->collect_stats)
+        return set_error(RT_ERR_INVALID_ARGUMENT, "rt_render_device_noalloc cannot collect stats (that needs a host synchronisation)");
+    if (opts && (opts->flags & RT_RENDER_TIMED))
+        return set_error(RT_ERR_INVALID_ARGUMENT, "rt_render_device_noalloc cannot time the launch (that needs event creation)");
+    const unsigned long long tiles = (unsigned long long)((camera->hsize + 7) / 8) * ((rows.n_rows + 7) / 8);
+    if (tiles > RT_NOALLOC_MAX_TILES)
+        return set_error(RT_ERR_CAPACITY, "the rows to render cover " + std::to_string(tiles) + " 8x8-pixel tiles; rt_render_device_noalloc's static scratch holds " +
+                                              std::to_string(RT_NOALLOC_MAX_TILES) + " (render fewer rows per call, or use rt_render_device)");
+    hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
+    DeviceGuard guard(scene->device);
+    if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+    // The device pointer that hipGetSymbolAddress returned for this GPU when the scene was created -- never the array's
+    // name, which is only a host-side handle.
+    uint32_t *tiles_ptr = nullptr;
+    if (scene->uneven && rows.n_rows && tile_order_enabled()) {
+        tiles_ptr = rt::static_render_scratch(scene->device);
+        if (!tiles_ptr) return set_error(RT_ERR_HIP, "the static scratch array could not be located on device " + std::to_string(scene->device));
+    }
+    if (opts && (opts->flags & RT_RENDER_QUANTIZED)) rows.quantized = reinterpret_cast<uint8_t *>(rgb_device);
+    // classify_tiles_kernel clears the words of the scratch that must start at zero (the census and the cursors);
+    // everything else the launch reads from it, it has written itself first.
+    HIP_TRY(rt::launch_render(scene->dev, cam, rows, depth, rgb_device, nullptr, tiles_ptr, stream, nullptr));
     return RT_OK;
 }
 

@@ -23,6 +23,7 @@
 
 #include <cstddef>
 #include <cstdlib>
+#include <mutex>
 
 #include "../../include/raytracer_rs_amd.h"
 #include "rt_device.hpp"
@@ -1555,6 +1556,41 @@ hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, co
     hipError_t launched = hipGetLastError();
     if (launched == hipSuccess && marks) launched = hipEventRecord(marks[2], stream);
     return launched;
+}
+
+// Tile-ordering scratch for callers that must not allocate (rt_render_device_noalloc): one array per GPU, held by
+// every GPU the library's code object is loaded on until the process ends.  In host code the name `scratch` is only a
+// handle for hipGetSymbolAddress -- it is NOT a device address; host code uses the pointer that call returned
+// (one per device: every GPU has its own copy of the array at its own address).
+static __device__ __align__(256) uint32_t scratch[TILE_HEADER + 3u * RT_NOALLOC_MAX_TILES];
+static_assert(sizeof(scratch) == RT_NOALLOC_SCRATCH_BYTES, "header and array disagree about the size of the static scratch");
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+uint32_t *g_static_scratch[MAX_DEVICES] = {};  // per device; written once, under g_static_scratch_mutex
+std::mutex g_static_scratch_mutex;
+}  // namespace
+
+hipError_t static_render_scratch_resolve(int device) {
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+    if (g_static_scratch[device]) return hipSuccess;
+    int current = -1;
+    hipError_t e = hipGetDevice(&current);
+    if (e != hipSuccess) return e;
+    if (current != device) return hipErrorInvalidDevice;  // the address is that of the CURRENT device's copy
+    uint32_t *ptr = nullptr;
+    e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    g_static_scratch[device] = ptr;
+    return hipSuccess;
+}
+
+uint32_t *static_render_scratch(int device) {
+    if (device < 0 || device >= MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+    return g_static_scratch[device];
 }
 
 hipError_t launch_color_at(const DeviceScene &scene, const double *rays, uint32_t n, int remaining, double *colors,

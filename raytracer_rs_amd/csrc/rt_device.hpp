@@ -43,6 +43,12 @@ size_t render_scratch_words(uint32_t hsize, uint32_t n_rows);
 hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows, int max_depth,
                          double *rgb, unsigned long long *counters, uint32_t *tile_scratch, hipStream_t stream,
                          hipEvent_t *marks = nullptr);
+// The tile-ordering scratch that lives in a static device array (one copy per GPU) instead of allocated memory:
+// static_render_scratch_resolve(device) looks its address up once per device -- call it with `device` current, at
+// set-up; static_render_scratch(device) returns that address afterwards (nullptr when it was never resolved).  The
+// array holds render_scratch_words() words for frames of up to RT_NOALLOC_MAX_TILES tiles.
+hipError_t static_render_scratch_resolve(int device);
+uint32_t *static_render_scratch(int device);
 // The canvas quantiser (rendering/canvas.rs:123-130) over n values in device memory.
 hipError_t launch_quantize(const double *rgb, size_t n, uint8_t *out, hipStream_t stream);
 // World::color_at for n rays.

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(rt):
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.rt_abi_version() == 2
+    assert lib.rt_abi_version() == 3
 
 
 def test_struct_sizes_match_the_header(rt):
