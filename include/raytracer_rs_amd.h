@@ -49,8 +49,9 @@ enum { RT_SPHERE = 0, RT_PLANE = 1, RT_CUBE = 2, RT_CYLINDER = 3, RT_CONE = 4, R
 /* enum PatternKind (scene/patterns.rs:13-32); RT_PATTERN_NONE is Option::None (scene/materials.rs:18) */
 enum { RT_PATTERN_NONE = -1, RT_PATTERN_STRIPE = 0, RT_PATTERN_GRADIENT = 1, RT_PATTERN_RING = 2, RT_PATTERN_CHECKERS = 3 };
 
-/* Groups may be nested this deep below a top-level group (a leaf inside a top-level group is at depth 1). */
-#define RT_MAX_GROUP_NESTING 3
+/* Groups may be nested this deep (a leaf inside a top-level group is at depth 1).  The reference recurses without a
+ * limit (rendering/world.rs:41-78); the device walks any depth with one loop and parks one ray per level, this many. */
+#define RT_MAX_GROUP_NESTING 16
 /* DEFAULT_MAX_REFLECTION_DEPTH == DEFAULT_MAX_REFRACTION_DEPTH (rendering/world.rs:11-12) */
 #define RT_DEFAULT_DEPTH 5
 #define RT_MAX_DEPTH 8

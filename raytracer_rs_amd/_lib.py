@@ -18,7 +18,7 @@ ERR_NAMES = {-1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NOT_INVERTIBLE", -3: "RT
              -5: "RT_ERR_IO", -6: "RT_ERR_PARSE", -7: "RT_ERR_UNSUPPORTED", -8: "RT_ERR_NO_DEVICE", -9: "RT_ERR_CAPACITY"}
 SPHERE, PLANE, CUBE, CYLINDER, CONE, GROUP = range(6)
 PATTERN_NONE, PATTERN_STRIPE, PATTERN_GRADIENT, PATTERN_RING, PATTERN_CHECKERS = -1, 0, 1, 2, 3
-MAX_GROUP_NESTING = 3
+MAX_GROUP_NESTING = 16
 DEFAULT_DEPTH = 5
 RENDER_TIMED = 1
 RENDER_QUANTIZED = 2

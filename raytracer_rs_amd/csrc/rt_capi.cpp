@@ -205,9 +205,10 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     sc->dev.surfaces = sc->d_surfaces;
     sc->dev.n_nodes = (int32_t)sc->flat.nodes.size();
     sc->dev.n_leaves = (int32_t)sc->flat.surfaces.size();
-    // range-skip nodes need the kernels that fetch whole node records, i.e. those built for at least one group level
+    // 0 selects the kernels built for tables of leaves only; a group (even a childless one at the top level) or a
+    // range-skip node needs the general ones
     sc->dev.max_nesting = (int32_t)sc->flat.max_nesting;
-    if (sc->flat.n_skip_nodes && sc->dev.max_nesting < 1) sc->dev.max_nesting = 1;
+    if ((sc->flat.n_skip_nodes || sc->flat.n_groups) && sc->dev.max_nesting < 1) sc->dev.max_nesting = 1;
     sc->dev.any_order = sc->flat.reordered ? 1 : 0;
     sc->dev.light = sc->flat.light;
     // In a flat scene without reflective or transparent surfaces every pixel costs one or two rays over the same

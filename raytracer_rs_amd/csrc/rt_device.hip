@@ -57,8 +57,14 @@ constexpr double AABB_EPS = 1e-10;    // geometry/bounds.rs:114
 constexpr double CHECKER_EPS = 1e-6;  // scene/patterns.rs:106
 constexpr int STACK_MAX = RT_MAX_DEPTH + 1;  // in memory: at most one parked ray per level, plus one while a hit pushes two
 constexpr int LDS_LEVELS = 2;                // of which the first ones are kept in LDS: 2 x 64 B per lane = 8 KB per wave
-constexpr unsigned RAY_STACK_LDS_BYTES_PER_WAVE = LDS_LEVELS * 8 * 64 * sizeof(double);
-extern __shared__ double ray_stack_lds[];    // dynamic: RAY_STACK_LDS_BYTES_PER_WAVE per wave of the workgroup
+// Dynamic LDS of every kernel here, per wave of the workgroup: the LDS levels of the pending-ray stack (kernels that
+// run radiance()), then the slot in which a traversal parks the level-1 ray while it walks a nested group (kernels
+// built for scenes with groups: 6 x 64 doubles = 3 KB).  11 KB per wave for the render kernel of a scene with groups.
+template <int NEST, bool RADIANCE>
+constexpr unsigned LDS_WAVE_DOUBLES = ((RADIANCE ? LDS_LEVELS * 8 : 0) + (NEST > 0 ? 6 : 0)) * 64;
+template <int NEST, bool RADIANCE>
+constexpr size_t lds_bytes(unsigned block) { return (size_t)(block / 64) * LDS_WAVE_DOUBLES<NEST, RADIANCE> * sizeof(double); }
+extern __shared__ double ray_stack_lds[];
 
 enum {
     C_RAYS = 0, C_PRIMARY, C_SHADOW, C_REFLECT, C_REFRACT,
@@ -146,6 +152,7 @@ struct SceneK {
     const RtSurface *surfaces;
     int n_nodes;
     int max_depth;
+    unsigned stack_base, park_base;  // this wave's parts of the dynamic LDS, in doubles from ray_stack_lds
     RtLight light;
 };
 
@@ -459,6 +466,17 @@ __device__ __forceinline__ void to_local(const NodeRaw &r, int xform, V3 o, V3 d
 // reference's linear shortcut are dealt with by the caller: no box bounds those hits.)  `inv` = 1/d per axis, by the
 // approximate reciprocal.  A NaN limit (no hit yet) rejects nothing; 0 * inf = NaN drops out of v_max_f64 / v_min_f64.
 constexpr double SKIP_REACH = 500.0;  // EPSILON * 500 / 0.99 < RT_SKIP_PAD / 1.9
+// 1/x for the slab test of a range-skip box.  The hardware reciprocal alone is good to about 2^-23 relative, and that
+// error is multiplied by the distance from the ray origin to the box: for a small box far away it would exceed the
+// box's padding.  One Newton step leaves about 2^-45.  Zero (reciprocal infinite: the axis then drops out of the
+// test, or rejects the box when the origin lies outside the slab) and anything else whose reciprocal is not finite
+// is passed through as the hardware gives it.
+__device__ __forceinline__ double skip_reciprocal(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r, 1.0);
+    const double refined = __builtin_fma(r, e, r);
+    return fabs(r) < (double)INFINITY ? refined : r;
+}
 __device__ __forceinline__ bool box_may_hit(const double (&bb)[6], V3 o, V3 inv, double dmax, double limit) {
     const double x0 = bb[0] - o.x, x1 = bb[3] - o.x, y0 = bb[1] - o.y, y1 = bb[4] - o.y, z0 = bb[2] - o.z, z1 = bb[5] - o.z;
     const double reach = fmax(fmax(fmax(fabs(x0), fabs(x1)), fmax(fabs(y0), fabs(y1))), fmax(fabs(z0), fabs(z1)));
@@ -470,143 +488,237 @@ __device__ __forceinline__ bool box_may_hit(const double (&bb)[6], V3 o, V3 inv,
     return !(out & (reach <= SKIP_REACH * dmax));
 }
 
-// World::intersect / collect_intersections (rendering/world.rs:27-78) over the node range [begin,end) at nesting
-// level D of a scene whose deepest level is NEST, for the lanes with `active` set.  begin, end and the running index
-// are wave-uniform.  `far`: hits beyond it do not matter to the caller (range-skip nodes use it; the t parameter is
-// the same in every space because directions are never renormalised).  Per node: take the ray into the node's space (this uses up the matrix), request the following
-// record into the registers the matrix occupied, then run the shape or bounds test while that request is in flight.
-template <int D, int NEST, bool STATS, class B>
-__device__ __forceinline__ void trace_range(const SceneK &S, int begin, int end, V3 o, V3 d, bool active, double far,
-                                            B &best, Ctr<STATS> &ctr, const NodeRaw *first = nullptr) {
-    constexpr bool WIDE = NEST > 0;
-    if (begin >= end) return;
-    // `first`: the record at `begin` when the caller has requested it already (a group's first child is the record
-    // after the group's own)
-    NodeRaw raw = first ? *first : node_fetch<WIDE>(S.nodes, begin);
+// The control words of a node record, moved to registers of their own: nothing of the record is needed once the ray
+// has been transformed, so the next record can be loaded where this one lies.
+// (readfirstlane on the operands: the asm wants scalar registers whatever the optimiser has come to believe about the
+// record; on values that already are in scalar registers it costs nothing.  The optimiser takes what an asm statement
+// returns for possibly divergent; these are wave-uniform.)
+struct NodeWords {
+    int tag, leaf, skip;
+    double a0, a1;
+};
+__device__ __forceinline__ NodeWords node_words(const NodeRaw &raw) {
+    auto pair = [](int lo, int hi) { return (long long)(((unsigned long long)(unsigned)uniform(hi) << 32) | (unsigned)uniform(lo)); };
+    long long w0, w1, w2, w3;
+    asm volatile("s_mov_b64 %0, %4\n\ts_mov_b64 %1, %5\n\ts_mov_b64 %2, %6\n\ts_mov_b64 %3, %7"
+                 : "=&s"(w0), "=&s"(w1), "=&s"(w2), "=&s"(w3)
+                 : "s"(pair(raw.b[8], raw.b[9])), "s"(pair(raw.b[10], raw.b[11])), "s"(pair(raw.b[12], raw.b[13])),
+                   "s"(pair(raw.b[14], raw.b[15])));
+    NodeWords w;
+    w.tag = uniform((int)w0);
+    w.leaf = uniform((int)w1);
+    w.skip = uniform((int)(w1 >> 32));
+    w.a0 = __builtin_bit_cast(double, w2);
+    w.a1 = __builtin_bit_cast(double, w3);
+    return w;
+}
+
+// Shape::local_intersect of the leaf kinds on the ray (lo, ld) in the leaf's own space.  Same dispatch twice: as a
+// chain that reaches the sphere test after one comparison (the flat scenes of the book are spheres and planes: -2 %
+// there, +30 % on a deep scene of cubes and cones), and as a switch, which the compiler turns into a balanced tree.
+template <bool SPHERE_FIRST, bool STATS, class B>
+__device__ __forceinline__ bool hit_leaf(int kind, int tag, V3 lo, V3 ld, double a0, double a1, bool on, int leaf, B &best) {
+    const bool closed = (tag & RT_NODE_CLOSED) != 0;
+    if constexpr (SPHERE_FIRST) {
+        if (kind == RT_SPHERE) return hit_sphere(lo, ld, on, leaf, best);
+        if (kind == RT_PLANE) return hit_plane(lo, ld, on, leaf, best);
+        if (kind == RT_CUBE) return hit_cube(lo, ld, on, leaf, best);
+        if (kind == RT_CYLINDER) return hit_cylinder<STATS, B>(lo, ld, a0, a1, closed, on, leaf, best);
+        return hit_cone<STATS, B>(lo, ld, a0, a1, closed, on, leaf, best);
+    } else {
+        switch (kind) {
+            case RT_SPHERE: return hit_sphere(lo, ld, on, leaf, best);
+            case RT_PLANE: return hit_plane(lo, ld, on, leaf, best);
+            case RT_CUBE: return hit_cube(lo, ld, on, leaf, best);
+            case RT_CYLINDER: return hit_cylinder<STATS, B>(lo, ld, a0, a1, closed, on, leaf, best);
+            default: return hit_cone<STATS, B>(lo, ld, a0, a1, closed, on, leaf, best);
+        }
+    }
+}
+
+// World::intersect (rendering/world.rs:27-36) over a node table WITHOUT groups or range-skip nodes: every record is a
+// leaf of the world's top-level list.  The running index is wave-uniform.  Per node: take the ray into the node's
+// space (this uses up the matrix), request the following record into the registers the matrix occupied, then run the
+// shape test while that request is in flight.  Lanes that are not `active` run the tests too (there is no cheaper
+// way to idle them); nobody reads their result.
+template <bool STATS, class B>
+__device__ __forceinline__ void trace_flat(const SceneK &S, V3 o, V3 d, bool active, B &best, Ctr<STATS> &ctr) {
+    const int end = S.n_nodes;
+    if (end <= 0) return;
+    NodeRaw raw = node_fetch<false>(S.nodes, 0);
     // Consume one word of the first record here, so that its arrival is awaited before the loop and not at the top
     // of every iteration (where the wait would also cover the request for the following record).
     asm volatile("" ::"s"(raw.b[8]));
-    V3 inv_d = mk(0.0, 0.0, 0.0);  // for range-skip nodes, computed at the first one met at this level
+    int i = 0;
+    while (i < end) {
+        const NodeWords w = node_words(raw);
+        const int xform = uniform(raw.b[9]);  // only read before the next record is requested
+        const int kind = w.tag & 0xff;
+        V3 lo, ld;
+        to_local(raw, xform, o, d, lo, ld);
+        asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(ld.x), "+v"(ld.y), "+v"(ld.z));  // the transform is complete
+        NodeRaw nraw = node_fetch<false>(S.nodes, i + 1);  // the table has one spare record at its end
+        RT_NODE_VISIT(2);
+        const bool any = hit_leaf<true, STATS, B>(kind, w.tag, lo, ld, w.a0, w.a1, true, w.leaf, best);
+        if (STATS && active) {
+            ctr.add(C_XFORM);
+            ctr.add(C_PRIM_TESTS + kind);
+            if (any) ctr.add(C_PRIM_HITS + kind);
+        }
+        // One definition of the closest hit per iteration: without it the optimiser carries two copies of (t, leaf)
+        // round the loop -- the one the tests read and the one the caller gets -- and moves both at every join.
+        pin(best);
+        raw = nraw;
+        i = uniform(i + 1);
+    }
+}
+
+// Where a traversal parks the ray of an outer sibling list while it walks a group's children: the ray of nesting
+// level 1 in the wave's LDS (field-major, one 8-byte column per lane: conflict-free), deeper levels in a per-lane
+// array in scratch memory (indexed by the wave-uniform level, so a whole wave's access is one contiguous run).  The
+// world-space ray (level 0) needs no parking: the caller's copy is alive throughout.
+constexpr int MAX_NEST = RT_MAX_GROUP_NESTING;
+struct ParkedRays {
+    double *lds;                   // this lane's column of the wave's parking slot (6 x 64 doubles)
+    double deep[MAX_NEST > 2 ? MAX_NEST - 2 : 1][6];
+    __device__ __forceinline__ void park(int level, V3 o, V3 d) {  // level >= 1
+        if (level == 1) {
+            lds[0 * 64] = o.x; lds[1 * 64] = o.y; lds[2 * 64] = o.z;
+            lds[3 * 64] = d.x; lds[4 * 64] = d.y; lds[5 * 64] = d.z;
+        } else {
+            double *e = deep[level - 2];
+            e[0] = o.x; e[1] = o.y; e[2] = o.z; e[3] = d.x; e[4] = d.y; e[5] = d.z;
+        }
+    }
+    __device__ __forceinline__ void fetch(int level, V3 &o, V3 &d) const {  // level >= 1
+        if (level == 1) {
+            o = mk(lds[0 * 64], lds[1 * 64], lds[2 * 64]);
+            d = mk(lds[3 * 64], lds[4 * 64], lds[5 * 64]);
+        } else {
+            const double *e = deep[level - 2];
+            o = mk(e[0], e[1], e[2]);
+            d = mk(e[3], e[4], e[5]);
+        }
+    }
+};
+
+// World::intersect / collect_intersections (rendering/world.rs:27-78) over a node table with groups and range-skip
+// nodes, as ONE loop over the table for every nesting level (the reference recurses, world.rs:66-68).  The table is
+// in depth-first order and every record carries its nesting level, so the walk needs no stack of list ends: a record
+// at a shallower level than the one being walked means the lists in between have ended.  State:
+//   i, level          wave-uniform: the record being visited and the nesting level of the sibling list it belongs to
+//   (co, cd)          the ray in the space of that list: the world ray taken through the local inverse of every
+//                     enclosing group, one after the other (world.rs:53-58)
+//   act               per lane: the deepest level at which the lane's ray has passed every enclosing group's bounds;
+//                     the lane takes part in the tests of the current list when act == level
+// Entering a group (ANY lane's ray passes its bounds) parks (co, cd) and continues with the group-space ray; leaving
+// fetches the parked ray back.  `far`: hits beyond it do not matter to the caller (range-skip nodes use it; the t
+// parameter is the same in every space because directions are never renormalised).  Per node as in trace_flat: ray
+// into the node's space, next record requested over the current one, test while the request is in flight.
+template <bool STATS, class B>
+__device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool active0, double far, B &best, Ctr<STATS> &ctr) {
+    const int end = S.n_nodes;
+    if (end <= 0) return;
+    NodeRaw raw = node_fetch<true>(S.nodes, 0);
+    asm volatile("" ::"s"(raw.b[8]));  // as in trace_flat
+    ParkedRays parked;
+    parked.lds = ray_stack_lds + S.park_base + (threadIdx.x & 63u);
+    V3 co = o, cd = d;
+    int level = 0;
+    int act = active0 ? 0 : -1;
+    V3 inv_d = mk(0.0, 0.0, 0.0);  // for range-skip nodes: 1/cd per axis, computed at the first one met after a change of level
     double dmax = 0.0;
     bool have_inv = false;
-    int i = begin;
+    int i = 0;
     while (i < end) {
-        // The control words move to registers of their own, so that nothing of the record is needed once the ray
-        // has been transformed and the next record can be loaded where this one lies.
-        // (readfirstlane on the operands: the asm wants scalar registers whatever the optimiser has come to believe
-        // about the record; on values that already are in scalar registers it costs nothing)
-        auto pair = [](int lo, int hi) { return (long long)(((unsigned long long)(unsigned)uniform(hi) << 32) | (unsigned)uniform(lo)); };
-        long long w0, w1, w2, w3;
-        asm volatile("s_mov_b64 %0, %4\n\ts_mov_b64 %1, %5\n\ts_mov_b64 %2, %6\n\ts_mov_b64 %3, %7"
-                     : "=&s"(w0), "=&s"(w1), "=&s"(w2), "=&s"(w3)
-                     : "s"(pair(raw.b[8], raw.b[9])), "s"(pair(raw.b[10], raw.b[11])), "s"(pair(raw.b[12], raw.b[13])),
-                       "s"(pair(raw.b[14], raw.b[15])));
-        // (the optimiser takes what an asm statement returns for possibly divergent; these are wave-uniform)
-        const int tag = uniform((int)w0), leaf = uniform((int)w1), skip = uniform((int)(w1 >> 32));
+        const NodeWords w = node_words(raw);
         const int xform = uniform(raw.b[9]);  // only read before the next record is requested
-        const double a0 = __builtin_bit_cast(double, w2), a1 = __builtin_bit_cast(double, w3);
-        const int kind = tag & 0xff;
+        const int kind = w.tag & 0xff;
+        const int lvl = (w.tag >> RT_NODE_LEVEL_SHIFT) & RT_NODE_LEVEL_MASK;
+        if (lvl < level) {  // wave-uniform: the list(s) being walked ended before this record
+            act = act > lvl ? lvl : act;
+            if (lvl == 0) {
+                co = o;
+                cd = d;
+            } else {
+                parked.fetch(lvl, co, cd);
+            }
+            level = lvl;
+            have_inv = false;
+        }
+        const bool active = act == level;
         // Everything that reads the first 96 bytes of the record happens before the next record is requested.
-        V3 lo = o, ld = d;
+        V3 lo = co, ld = cd;
         bool shortcut = false;  // a cone below this range-skip node takes the reference's linear shortcut for this ray
-        if (WIDE && kind == RT_SKIPBOX) {
-            if constexpr (WIDE && !STATS && !B::every) {
+        if (kind == RT_SKIPBOX) {
+            if constexpr (!STATS && !B::every) {
                 if (xform == RT_SKIP_CONES) {
                     double m[7];
 #pragma unroll
                     for (int k = 0; k < 7; ++k) m[k] = dwords_to_double(raw.a[2 * k], raw.a[2 * k + 1]);
-                    const double qdd = (m[0] * d.x + m[1] * d.y + m[2] * d.z) * d.x + (m[1] * d.x + m[3] * d.y + m[4] * d.z) * d.y +
-                                       (m[2] * d.x + m[4] * d.y + m[5] * d.z) * d.z;
+                    const double qdd = (m[0] * cd.x + m[1] * cd.y + m[2] * cd.z) * cd.x + (m[1] * cd.x + m[3] * cd.y + m[4] * cd.z) * cd.y +
+                                       (m[2] * cd.x + m[4] * cd.y + m[5] * cd.z) * cd.z;
                     shortcut = !(fabs(qdd) >= m[6]);
                 }
             }
         } else {
-            to_local(raw, xform, o, d, lo, ld);
+            to_local(raw, xform, co, cd, lo, ld);
         }
         double bb[6];
-        if constexpr (WIDE) {
-            bb[0] = a0;
-            bb[1] = a1;
+        bb[0] = w.a0;
+        bb[1] = w.a1;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) bb[2 + k] = dwords_to_double(raw.c[2 * k], raw.c[2 * k + 1]);
-        }
+        for (int k = 0; k < 4; ++k) bb[2 + k] = dwords_to_double(raw.c[2 * k], raw.c[2 * k + 1]);
         // The record to have ready next: the following one -- except after a range-skip node, which more often
         // than not sends the traversal to `skip` (the table has one spare record at its end).
-        const int guess = (WIDE && kind == RT_SKIPBOX && !STATS && !B::every) ? skip : i + 1;
+        const int guess = (kind == RT_SKIPBOX && !STATS && !B::every) ? w.skip : i + 1;
         asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(ld.x), "+v"(ld.y), "+v"(ld.z));  // the transform is complete
-        NodeRaw nraw = node_fetch<WIDE>(S.nodes, guess);
+        NodeRaw nraw = node_fetch<true>(S.nodes, guess);
         int ni = i + 1;
         RT_NODE_VISIT(kind == RT_SKIPBOX ? 0 : kind == RT_GROUP ? 1 : 2);
-        if (WIDE && kind == RT_SKIPBOX) {
-            if constexpr (WIDE && !STATS && !B::every) {  // the counting kernel visits everything the reference visits
+        if (kind == RT_SKIPBOX) {
+            if constexpr (!STATS && !B::every) {  // the counting kernel visits everything the reference visits
                 if (!have_inv) {
-                    inv_d = mk(__builtin_amdgcn_rcp(d.x), __builtin_amdgcn_rcp(d.y), __builtin_amdgcn_rcp(d.z));
-                    dmax = fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z));
+                    inv_d = mk(skip_reciprocal(cd.x), skip_reciprocal(cd.y), skip_reciprocal(cd.z));
+                    dmax = fmax(fmax(fabs(cd.x), fabs(cd.y)), fabs(cd.z));
                     have_inv = true;
                 }
-                const bool may = active && !settled(best) && (shortcut || box_may_hit(bb, o, inv_d, dmax, hit_limit(best, far)));
+                const bool may = active && !settled(best) && (shortcut || box_may_hit(bb, co, inv_d, dmax, hit_limit(best, far)));
                 ctr.visits += may ? 1u : 0u;
-                if (__ballot(may) == 0ull) ni = skip;
+                if (__ballot(may) == 0ull) ni = w.skip;
             }
-        } else if (D < NEST && kind == RT_GROUP) {
-            if constexpr (D < NEST) {
-                bool inside = false;
-                if (active) {
-                    inside = aabb_hit(bb, lo, ld);
-                    ctr.add(C_XFORM);
-                    ctr.add(C_AABB);
-                }
-                if constexpr (!STATS) ctr.visits += inside ? 4u : 0u;
-                if (__ballot(inside) != 0ull) trace_range<D + 1, NEST, STATS, B>(S, i + 1, skip, lo, ld, inside, far, best, ctr, &nraw);
-                ni = skip;
+        } else if (kind == RT_GROUP) {
+            // Group: bounds in the group's own space against the ray in that space (world.rs:44-63)
+            bool inside = false;
+            if (active) {
+                inside = aabb_hit(bb, lo, ld);
+                ctr.add(C_XFORM);
+                ctr.add(C_AABB);
             }
-        } else if (kind != RT_GROUP) {
-            // Lanes that are not `active` run the test too (there is no cheaper way to idle them) but cannot
-            // change their closest hit.  At the top level the inactive lanes are the ones whose result nobody
-            // reads: no mask needed there.
-            const bool on = D == 0 ? true : active;
-            bool any;
-            // Same dispatch twice: as a chain that reaches the sphere test after one comparison (the flat scenes of
-            // the book are spheres and planes: -2 % there, +30 % on a deep scene of cubes and cones), and as a switch,
-            // which the compiler turns into a balanced tree of comparisons.
-            if constexpr (NEST == 0) {
-                if (kind == RT_SPHERE) any = hit_sphere(lo, ld, on, leaf, best);
-                else if (kind == RT_PLANE) any = hit_plane(lo, ld, on, leaf, best);
-                else if (kind == RT_CUBE) any = hit_cube(lo, ld, on, leaf, best);
-                else if (kind == RT_CYLINDER) any = hit_cylinder<STATS, B>(lo, ld, a0, a1, (tag & RT_NODE_CLOSED) != 0, on, leaf, best);
-                else any = hit_cone<STATS, B>(lo, ld, a0, a1, (tag & RT_NODE_CLOSED) != 0, on, leaf, best);
-            } else {
-                switch (kind) {
-                    case RT_SPHERE: any = hit_sphere(lo, ld, on, leaf, best); break;
-                    case RT_PLANE: any = hit_plane(lo, ld, on, leaf, best); break;
-                    case RT_CUBE: any = hit_cube(lo, ld, on, leaf, best); break;
-                    case RT_CYLINDER: any = hit_cylinder<STATS, B>(lo, ld, a0, a1, (tag & RT_NODE_CLOSED) != 0, on, leaf, best); break;
-                    default: any = hit_cone<STATS, B>(lo, ld, a0, a1, (tag & RT_NODE_CLOSED) != 0, on, leaf, best); break;
-                }
+            if constexpr (!STATS) ctr.visits += inside ? 4u : 0u;
+            ni = w.skip;
+            if (__ballot(inside) != 0ull && w.skip != i + 1) {  // (a group without children has nothing to walk)
+                if (level > 0) parked.park(level, co, cd);
+                co = lo;
+                cd = ld;
+                level = level + 1;
+                act = inside ? level : act;
+                have_inv = false;
+                ni = i + 1;
             }
+        } else {
+            const bool any = hit_leaf<false, STATS, B>(kind, w.tag, lo, ld, w.a0, w.a1, active, w.leaf, best);
             if (STATS && active) {
                 ctr.add(C_XFORM);
                 ctr.add(C_PRIM_TESTS + kind);
                 if (any) ctr.add(C_PRIM_HITS + kind);
             }
-        } else {
-            // A group at the deepest level the scene declares has no children; the reference still transforms the
-            // ray and tests the (empty, always passing) bounds before it finds that out (world.rs:53-58).
-            if (STATS && active) {
-                ctr.add(C_XFORM);
-                ctr.add(C_AABB);
-            }
-            ni = skip;
         }
-        if constexpr (NEST > 0) {
-            if (ni != guess) {
-                nraw = node_fetch<WIDE>(S.nodes, ni);  // guessed wrong: fetch the record wanted
-                RT_NODE_VISIT(3);
-            }
+        if (ni != guess) {
+            nraw = node_fetch<true>(S.nodes, ni);  // guessed wrong: fetch the record wanted
+            RT_NODE_VISIT(3);
         }
-        // One definition of the closest hit per iteration: without it the optimiser carries two copies of (t, leaf)
-        // round the loop -- the one the tests read and the one the caller gets -- and moves both at every join.
-        pin(best);
+        pin(best);  // as in trace_flat
         raw = nraw;
         i = uniform(ni);  // every operand above is wave-uniform; keep the index in an SGPR
     }
@@ -618,7 +730,8 @@ __device__ __forceinline__ Closest<TIES> trace(const SceneK &S, V3 o, V3 d, bool
     best.t = __builtin_nan("");
     best.leaf = -1;
     if (STATS && active) ctr.add(C_RAYS);
-    trace_range<0, NEST, STATS, Closest<TIES>>(S, 0, S.n_nodes, o, d, active, far, best, ctr);
+    if constexpr (NEST == 0) trace_flat<STATS>(S, o, d, active, best, ctr);
+    else trace_nested<STATS>(S, o, d, active, far, best, ctr);
     return best;
 }
 
@@ -629,7 +742,8 @@ __device__ __forceinline__ bool occluded(const SceneK &S, V3 o, V3 d, bool activ
     oc.far = distance;
     oc.t = __builtin_nan("");
     if (STATS && active) ctr.add(C_RAYS);
-    trace_range<0, NEST, STATS, Occluded>(S, 0, S.n_nodes, o, d, active, distance, oc, ctr);
+    if constexpr (NEST == 0) trace_flat<STATS>(S, o, d, active, oc, ctr);
+    else trace_nested<STATS>(S, o, d, active, distance, oc, ctr);
     return oc.t < distance;
 }
 
@@ -799,7 +913,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
     V3 nx_o = mk(0, 0, 0), nx_d = mk(0, 0, 0);
     double nx_w = 0.0;
     int nx_rem = -1;
-    double *const lds = ray_stack_lds + (threadIdx.x & ~63u) * (LDS_LEVELS * 8) + (threadIdx.x & 63u);
+    double *const lds = ray_stack_lds + S.stack_base + (threadIdx.x & 63u);
     double stk[STACK_MAX - LDS_LEVELS][7];
     int stk_rem[STACK_MAX - LDS_LEVELS];
     int sp = 0;
@@ -997,12 +1111,15 @@ __device__ __forceinline__ void flush_counters<true>(Ctr<true> &ctr, unsigned lo
     }
 }
 
+template <int NEST, bool RADIANCE>
 __device__ __forceinline__ SceneK scene_k(const DeviceScene &d, int max_depth) {
     SceneK S;
     S.nodes = (NodeP)d.nodes;
     S.surfaces = d.surfaces;
     S.n_nodes = d.n_nodes;
     S.max_depth = max_depth;
+    S.stack_base = (unsigned)uniform((int)(threadIdx.x >> 6)) * LDS_WAVE_DOUBLES<NEST, RADIANCE>;
+    S.park_base = S.stack_base + (RADIANCE ? LDS_LEVELS * 8 * 64 : 0);
     S.light = d.light;
     return S;
 }
@@ -1073,7 +1190,7 @@ __global__ __launch_bounds__(256) void classify_tiles_kernel(DeviceScene scene, 
     unsigned x = (tile % tiles_x) * 8 + 4, r = (tile / tiles_x) * 8 + 4;
     if (x >= cam.hsize) x = cam.hsize - 1;
     if (r >= rows.n_rows) r = rows.n_rows - 1;
-    SceneK S = scene_k(scene, 0);
+    SceneK S = scene_k<NEST, false>(scene, 0);
     Ctr<false> ctr;
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     if (valid) ray_for_pixel(cam, x, image_row(rows, r), ro, rd);
@@ -1185,7 +1302,7 @@ __global__ __launch_bounds__(256, 4) void render_kernel(DeviceScene scene, RtCam
     const unsigned r = (tile / tiles_x) * 8 + (lane >> 3);  // row in the packed output
     const unsigned y = image_row(rows, r);
     const bool valid = x < cam.hsize && r < rows.n_rows && y < rows.row_end;
-    SceneK S = scene_k(scene, max_depth);
+    SceneK S = scene_k<NEST, true>(scene, max_depth);
     Ctr<STATS> ctr;
     ctr.clear();
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
@@ -1216,7 +1333,7 @@ __global__ __launch_bounds__(256) void color_at_kernel(DeviceScene scene, const 
                                                        unsigned long long *counters) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
-    SceneK S = scene_k(scene, remaining);
+    SceneK S = scene_k<NEST, true>(scene, remaining);
     Ctr<STATS> ctr;
     ctr.clear();
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
@@ -1238,14 +1355,14 @@ __global__ __launch_bounds__(256) void intersect_kernel(DeviceScene scene, const
                                                         double *__restrict__ t, int *__restrict__ object) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
-    SceneK S = scene_k(scene, 0);
+    SceneK S = scene_k<1, false>(scene, 0);
     Ctr<false> ctr;
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     if (valid) {
         ro = mk(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]);
         rd = mk(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
     }
-    const Closest<true> best = trace<RT_MAX_GROUP_NESTING, false>(S, ro, rd, valid, (double)INFINITY, ctr);
+    const Closest<true> best = trace<1, false>(S, ro, rd, valid, (double)INFINITY, ctr);
     if (valid) {
         t[i] = best.leaf >= 0 ? best.t : __builtin_nan("");
         object[i] = best.leaf >= 0 ? S.surfaces[best.leaf].object : -1;
@@ -1262,7 +1379,7 @@ __global__ __launch_bounds__(256) void intersect_all_kernel(DeviceScene scene, c
                                                             double *__restrict__ t, int *__restrict__ object) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
-    SceneK S = scene_k(scene, 0);
+    SceneK S = scene_k<1, false>(scene, 0);
     Ctr<false> ctr;
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     AllHits all;
@@ -1274,7 +1391,7 @@ __global__ __launch_bounds__(256) void intersect_all_kernel(DeviceScene scene, c
         ro = mk(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]);
         rd = mk(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
     }
-    trace_range<0, RT_MAX_GROUP_NESTING, false, AllHits>(S, 0, S.n_nodes, ro, rd, valid, (double)INFINITY, all, ctr);
+    trace_nested<false>(S, ro, rd, valid, (double)INFINITY, all, ctr);
     if (!valid) return;
     count[i] = all.count;
     const unsigned m = all.count < cap ? all.count : cap;
@@ -1348,7 +1465,7 @@ __global__ __launch_bounds__(256) void shade_part_kernel(DeviceScene scene, cons
                                                          int remaining, double *__restrict__ colors) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
-    SceneK S = scene_k(scene, remaining);
+    SceneK S = scene_k<NEST, true>(scene, remaining);
     Ctr<false> ctr;
     const RtComps &c = comps[valid ? i : 0];
     const RtSurface *s = S.surfaces + c.object;
@@ -1412,7 +1529,7 @@ __global__ __launch_bounds__(256) void is_shadowed_kernel(DeviceScene scene, con
                                                           unsigned n, uint8_t *__restrict__ out) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
-    SceneK S = scene_k(scene, 0);
+    SceneK S = scene_k<1, false>(scene, 0);
     Ctr<false> ctr;
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     double distance = 0.0;
@@ -1423,7 +1540,7 @@ __global__ __launch_bounds__(256) void is_shadowed_kernel(DeviceScene scene, con
         distance = magnitude(v);
         rd = div_by_magnitude(v, distance);
     }
-    const bool hit = occluded<RT_MAX_GROUP_NESTING, false>(S, ro, rd, valid && lit_world, distance, ctr);
+    const bool hit = occluded<1, false>(S, ro, rd, valid && lit_world, distance, ctr);
     if (valid) out[i] = (lit_world && hit) ? 1 : 0;
 }
 
@@ -1478,38 +1595,21 @@ inline unsigned blocks_for(unsigned n) { return (n + 255u) / 256u; }
 
 }  // namespace
 
-// The kernels are compiled once per nesting depth of the scene (0 = no groups at all): registers for the rays of
-// levels a scene does not have are never allocated, and a flat scene carries no group code.
+// The kernels exist in two builds: for scenes without groups (NEST = 0: every record a leaf, no group or range-skip
+// code, the lean 128-byte record fetch) and for everything else (NEST = 1: one loop over the table whatever the depth
+// of nesting).
 template <bool STATS>
 static void launch_render_nest(int nest, dim3 grid, unsigned block, hipStream_t stream, const DeviceScene &scene, const RtCameraDev &camera,
                                const RowMap &rows, int max_depth, double *rgb, unsigned long long *counters) {
-    const size_t lds = (block / 64) * RAY_STACK_LDS_BYTES_PER_WAVE;
-#define RT_LAUNCH(N, T) render_kernel<STATS, N, T><<<grid, block, lds, stream>>>(scene, camera, rows, max_depth, rgb, counters)
+#define RT_LAUNCH(N, T) render_kernel<STATS, N, T><<<grid, block, lds_bytes<N, true>(block), stream>>>(scene, camera, rows, max_depth, rgb, counters)
     if (nest == 0) {
         RT_LAUNCH(0, false);
         return;
     }
     // The counting variant always breaks ties by leaf number (right for any table order, and its speed does not
     // matter); the plain one only when the host reordered a sibling list, because the comparison is paid per candidate.
-    if constexpr (STATS) {
-        switch (nest) {
-            case 1: RT_LAUNCH(1, true); break;
-            case 2: RT_LAUNCH(2, true); break;
-            default: RT_LAUNCH(RT_MAX_GROUP_NESTING, true); break;
-        }
-    } else if (scene.any_order != 0) {
-        switch (nest) {
-            case 1: RT_LAUNCH(1, true); break;
-            case 2: RT_LAUNCH(2, true); break;
-            default: RT_LAUNCH(RT_MAX_GROUP_NESTING, true); break;
-        }
-    } else {
-        switch (nest) {
-            case 1: RT_LAUNCH(1, false); break;
-            case 2: RT_LAUNCH(2, false); break;
-            default: RT_LAUNCH(RT_MAX_GROUP_NESTING, false); break;
-        }
-    }
+    if (STATS || scene.any_order != 0) RT_LAUNCH(1, true);
+    else RT_LAUNCH(1, false);
 #undef RT_LAUNCH
 }
 
@@ -1531,12 +1631,8 @@ hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, co
     }
     if (tile_scratch) {
         const dim3 cgrid(blocks_for(rows.n_tiles));
-        switch (scene.max_nesting) {
-            case 0: classify_tiles_kernel<0><<<cgrid, 256, 0, stream>>>(scene, camera, rows, tile_scratch); break;
-            case 1: classify_tiles_kernel<1><<<cgrid, 256, 0, stream>>>(scene, camera, rows, tile_scratch); break;
-            case 2: classify_tiles_kernel<2><<<cgrid, 256, 0, stream>>>(scene, camera, rows, tile_scratch); break;
-            default: classify_tiles_kernel<RT_MAX_GROUP_NESTING><<<cgrid, 256, 0, stream>>>(scene, camera, rows, tile_scratch); break;
-        }
+        if (scene.max_nesting == 0) classify_tiles_kernel<0><<<cgrid, 256, lds_bytes<0, false>(256), stream>>>(scene, camera, rows, tile_scratch);
+        else classify_tiles_kernel<1><<<cgrid, 256, lds_bytes<1, false>(256), stream>>>(scene, camera, rows, tile_scratch);
         const dim3 ogrid((rows.n_tiles + ORDER_BLOCK - 1) / ORDER_BLOCK);
         order_count_kernel<<<ogrid, ORDER_BLOCK, 0, stream>>>(rows, (camera.hsize + 7) / 8, tile_scratch);
         order_scatter_kernel<<<ogrid, ORDER_BLOCK, 0, stream>>>(rows, tile_scratch);
@@ -1598,11 +1694,11 @@ hipError_t launch_color_at(const DeviceScene &scene, const double *rays, uint32_
     if (n == 0) return hipSuccess;
     const bool flat = scene.max_nesting == 0;
     if (counters) {
-        if (flat) color_at_kernel<true, 0><<<blocks_for(n), 256, 4 * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, rays, n, remaining, colors, counters);
-        else color_at_kernel<true, RT_MAX_GROUP_NESTING><<<blocks_for(n), 256, 4 * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, rays, n, remaining, colors, counters);
+        if (flat) color_at_kernel<true, 0><<<blocks_for(n), 256, lds_bytes<0, true>(256), stream>>>(scene, rays, n, remaining, colors, counters);
+        else color_at_kernel<true, 1><<<blocks_for(n), 256, lds_bytes<1, true>(256), stream>>>(scene, rays, n, remaining, colors, counters);
     } else {
-        if (flat) color_at_kernel<false, 0><<<blocks_for(n), 256, 4 * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, rays, n, remaining, colors, nullptr);
-        else color_at_kernel<false, RT_MAX_GROUP_NESTING><<<blocks_for(n), 256, 4 * RAY_STACK_LDS_BYTES_PER_WAVE, stream>>>(scene, rays, n, remaining, colors, nullptr);
+        if (flat) color_at_kernel<false, 0><<<blocks_for(n), 256, lds_bytes<0, true>(256), stream>>>(scene, rays, n, remaining, colors, nullptr);
+        else color_at_kernel<false, 1><<<blocks_for(n), 256, lds_bytes<1, true>(256), stream>>>(scene, rays, n, remaining, colors, nullptr);
     }
     return hipGetLastError();
 }
@@ -1610,14 +1706,14 @@ hipError_t launch_color_at(const DeviceScene &scene, const double *rays, uint32_
 hipError_t launch_intersect(const DeviceScene &scene, const double *rays, uint32_t n, double *t, int32_t *object,
                             hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    intersect_kernel<<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, t, object);
+    intersect_kernel<<<blocks_for(n), 256, lds_bytes<1, false>(256), stream>>>(scene, rays, n, t, object);
     return hipGetLastError();
 }
 
 hipError_t launch_intersect_all(const DeviceScene &scene, const double *rays, uint32_t n, uint32_t cap, uint32_t *count,
                                 double *t, int32_t *object, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    intersect_all_kernel<<<blocks_for(n), 256, 0, stream>>>(scene, rays, n, cap, count, t, object);
+    intersect_all_kernel<<<blocks_for(n), 256, lds_bytes<1, false>(256), stream>>>(scene, rays, n, cap, count, t, object);
     return hipGetLastError();
 }
 
@@ -1630,9 +1726,8 @@ hipError_t launch_prepare_computations(const DeviceScene &scene, const double *r
 
 template <int PART>
 static void launch_part(const DeviceScene &scene, const RtComps *comps, uint32_t n, int remaining, double *colors, hipStream_t stream) {
-    const size_t lds = 4 * RAY_STACK_LDS_BYTES_PER_WAVE;
-    if (scene.max_nesting == 0) shade_part_kernel<PART, 0><<<blocks_for(n), 256, lds, stream>>>(scene, comps, n, remaining, colors);
-    else shade_part_kernel<PART, RT_MAX_GROUP_NESTING><<<blocks_for(n), 256, lds, stream>>>(scene, comps, n, remaining, colors);
+    if (scene.max_nesting == 0) shade_part_kernel<PART, 0><<<blocks_for(n), 256, lds_bytes<0, true>(256), stream>>>(scene, comps, n, remaining, colors);
+    else shade_part_kernel<PART, 1><<<blocks_for(n), 256, lds_bytes<1, true>(256), stream>>>(scene, comps, n, remaining, colors);
 }
 
 hipError_t launch_shade_part(const DeviceScene &scene, int part, const RtComps *comps, uint32_t n, int remaining,
@@ -1650,7 +1745,7 @@ hipError_t launch_shade_part(const DeviceScene &scene, int part, const RtComps *
 hipError_t launch_is_shadowed(const DeviceScene &scene, const double *points, uint32_t n, uint8_t *out,
                               hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    is_shadowed_kernel<<<blocks_for(n), 256, 0, stream>>>(scene, points, n, out);
+    is_shadowed_kernel<<<blocks_for(n), 256, lds_bytes<1, false>(256), stream>>>(scene, points, n, out);
     return hipGetLastError();
 }
 

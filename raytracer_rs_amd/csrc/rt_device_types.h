@@ -22,7 +22,8 @@ enum { RT_XFORM_GENERAL = 0, RT_XFORM_DIAGONAL = 1 /* scale + translation */, RT
 
 struct RtNode {
     double inv[12];   // rows 0..2 of inverse(transformation), row-major 3x4
-    int32_t tag;      // RT_SPHERE .. RT_GROUP or RT_SKIPBOX in bits 0..7; bit 8: cylinder / cone is closed
+    int32_t tag;      // RT_SPHERE .. RT_GROUP or RT_SKIPBOX in bits 0..7; bit 8: cylinder / cone is closed;
+                      // bits 9..15: nesting level of the sibling list the node belongs to (0 = the world's own list)
     int32_t xform;    // RT_XFORM_*
     int32_t leaf;     // index into RtSurface[], -1 for groups
     int32_t skip;     // index of the first node after this node's subtree
@@ -30,6 +31,8 @@ struct RtNode {
                       // range-skip node: box min.xyz, max.xyz
 };
 #define RT_NODE_CLOSED 0x100
+#define RT_NODE_LEVEL_SHIFT 9
+#define RT_NODE_LEVEL_MASK 0x7f
 // A node kind of this table only (the reference has no such object): a conservative box, in the space of the
 // sibling list it stands in, around the nodes (i, skip).  When no ray of a wave can touch the box the traversal
 // continues at `skip`; otherwise at i + 1, with the same ray.  Its matrix is the identity and it has no leaf.

@@ -158,6 +158,7 @@ struct Builder {
         const rt_object_desc &o = world.objects[idx];
         if (o.kind < RT_SPHERE || o.kind > RT_GROUP) return fail(RT_ERR_INVALID_ARGUMENT, "object #%u has an unknown kind", idx);
         if (depth > out.max_nesting) out.max_nesting = depth;
+        if (depth > RT_MAX_GROUP_NESTING) return fail(RT_ERR_UNSUPPORTED, "groups are nested too deep at object #%u", idx);
         if (o.kind == RT_GROUP) {
             if (o.n_children < 0) return fail(RT_ERR_INVALID_ARGUMENT, "group #%u has a negative child count", idx);
             Bounds gb = Bounds::empty();
@@ -212,10 +213,10 @@ struct Builder {
         return true;
     }
 
-    void push_skip(const double box[6], const ConeDirs &dirs) {
+    void push_skip(const double box[6], const ConeDirs &dirs, uint32_t depth) {
         RtNode head;
         std::memset(&head, 0, sizeof head);
-        head.tag = RT_SKIPBOX;
+        head.tag = RT_SKIPBOX | (int32_t)(depth << RT_NODE_LEVEL_SHIFT);
         head.xform = RT_SKIP_PLAIN;
         if (dirs.any) {  // inv[0..5] = q, inv[6] = bound on |d^T q d| below which the node lets a ray through
             head.xform = RT_SKIP_CONES;
@@ -318,7 +319,7 @@ struct Builder {
                 ConeDirs dirs;
                 const bool wrap = (!whole_list || out.max_nesting >= 1) && kind != RT_SPHERE && kind != RT_PLANE && skip_box(list, k, k + 1, box, dirs);
                 const size_t ni = out.nodes.size();
-                if (wrap) push_skip(box, dirs);
+                if (wrap) push_skip(box, dirs, depth);
                 if (!emit(list[k], depth)) return false;
                 if (wrap) out.nodes[ni].skip = (int32_t)out.nodes.size();
             }
@@ -331,7 +332,7 @@ struct Builder {
             ConeDirs dirs;
             if (pb - pa >= 2 && skip_box(list, pa, pb, box, dirs)) {
                 const size_t ni = out.nodes.size();
-                push_skip(box, dirs);
+                push_skip(box, dirs, depth);
                 if (!emit_range(list, pa, pb, depth)) return false;
                 out.nodes[ni].skip = (int32_t)out.nodes.size();
             } else if (!emit_range(list, pa, pb, depth)) {
@@ -355,7 +356,7 @@ struct Builder {
             std::memset(&n, 0, sizeof n);
             rows3(*Tinv, n.inv);
             n.xform = classify(n.inv);
-            n.tag = o.kind | (o.closed ? RT_NODE_CLOSED : 0);
+            n.tag = o.kind | (o.closed ? RT_NODE_CLOSED : 0) | (int32_t)(depth << RT_NODE_LEVEL_SHIFT);
             n.leaf = -1;
         }
 

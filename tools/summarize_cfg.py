@@ -125,18 +125,22 @@ def main() -> None:
     lines += ["## Derived", ""] + [f"* {d}" for d in derived] + [""]
 
     if a.resource_usage and kernel_full:
-        want = short_name(kernel_full).replace("rt::", "")
+        import subprocess
+
+        want = short_name(kernel_full)
         with open(a.resource_usage) as f:
             text = f.read()
         block, keep = [], False
         for ln in text.splitlines():
-            m = re.search(r"remark: .*Function Name: (.*)", ln)
+            m = re.search(r"remark: Function Name: (\S+)", ln)
             if m:
-                keep = want in m.group(1)  # mangled names contain the template arguments as digits; match loosely below
+                demangled = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+                keep = short_name(demangled) == want
+                if keep:
+                    block.append(short_name(demangled))
+                continue
             if keep and "remark:" in ln:
-                block.append(ln.split("remark:", 1)[1].strip())
-        if not block:  # mangled names: pick the block by the demangled comment the Makefile target adds
-            block = [ln for ln in text.splitlines() if want in ln]
+                block.append(ln.split("remark:", 1)[1].replace("[-Rpass-analysis=kernel-resource-usage]", "").rstrip())
         lines += ["## Compiler resource usage (`-Rpass-analysis=kernel-resource-usage`)", "", "```"] + block + ["```", ""]
 
     with open(os.path.join(dst, f"{a.tag}_summary.md"), "w") as f:
