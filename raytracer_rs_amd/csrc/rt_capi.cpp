@@ -168,7 +168,7 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     std::string err;
     int rc = rt::flatten_world(*world, sc->flat, err);
     if (rc != RT_OK) return set_error(rc, err);
-    if ((sc->flat.nodes.size() + 1) * sizeof(RtNode) >= (1ull << 32))  // the traversal addresses records by 32-bit byte offsets
+    if (sc->flat.nodes.size() * sizeof(RtNode) >= (1ull << 32))  // the traversal addresses records by 32-bit byte offsets
         return set_error(RT_ERR_UNSUPPORTED, "the world has too many objects for one node table (4 GB of records)");
     sc->object_to_leaf.assign(world->n_objects, -1);
     for (size_t leaf = 0; leaf < sc->flat.surfaces.size(); ++leaf)
@@ -188,9 +188,7 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     (void)rt::static_render_scratch_resolve(device);
 
     size_t nb = sc->flat.nodes.size() * sizeof(RtNode), sb = sc->flat.surfaces.size() * sizeof(RtSurface);
-    // one inert record past the end: the traversal prefetches node i+1 while it works on node i
-    e = hipMalloc((void **)&sc->d_nodes, nb + sizeof(RtNode));
-    if (e == hipSuccess) e = hipMemset((char *)sc->d_nodes + nb, 0, sizeof(RtNode));
+    e = hipMalloc((void **)&sc->d_nodes, nb);  // (every table carries its own inert trailing record)
     if (e == hipSuccess) e = hipMalloc((void **)&sc->d_surfaces, sb ? sb : sizeof(RtSurface));
     if (e == hipSuccess) e = hipMalloc((void **)&sc->d_counters, RT_NUM_COUNTERS * sizeof(unsigned long long));
     if (e == hipSuccess && nb) e = hipMemcpy(sc->d_nodes, sc->flat.nodes.data(), nb, hipMemcpyHostToDevice);
@@ -200,10 +198,13 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
         rt_scene_destroy(raw);
         return hip_error(e, "uploading the scene");
     }
-    sc->device_bytes = nb + sizeof(RtNode) + sb + RT_NUM_COUNTERS * sizeof(unsigned long long);
+    sc->device_bytes = nb + sb + RT_NUM_COUNTERS * sizeof(unsigned long long);
     sc->dev.nodes = sc->d_nodes;
     sc->dev.surfaces = sc->d_surfaces;
-    sc->dev.n_nodes = (int32_t)sc->flat.nodes.size();
+    sc->dev.n_nodes = (int32_t)sc->flat.table_records - 1;
+    sc->dev.table_records = sc->flat.table_records;
+    sc->dev.oct_tables = 0;
+    for (int oct = 0; oct < 8; ++oct) sc->dev.oct_tables |= (unsigned long long)sc->flat.oct_table[oct] << (8 * oct);
     sc->dev.n_leaves = (int32_t)sc->flat.surfaces.size();
     // 0 selects the kernels built for tables of leaves only; a group (even a childless one at the top level) or a
     // range-skip node needs the general ones
@@ -237,7 +238,7 @@ void rt_scene_destroy(rt_scene *scene) {
 int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out) {
     if (!scene || !out) return set_error(RT_ERR_INVALID_ARGUMENT, "scene and out must not be NULL");
     std::memset(out, 0, sizeof *out);
-    out->n_objects = (uint32_t)(scene->flat.nodes.size() - scene->flat.n_skip_nodes);
+    out->n_objects = (uint32_t)(scene->flat.table_records - 1 - scene->flat.n_skip_nodes);
     out->n_leaves = scene->flat.n_leaves;
     out->n_groups = scene->flat.n_groups;
     out->max_nesting = scene->flat.max_nesting;

@@ -153,6 +153,8 @@ struct SceneK {
     int n_nodes;
     int max_depth;
     unsigned stack_base, park_base;  // this wave's parts of the dynamic LDS, in doubles from ray_stack_lds
+    unsigned table_bytes;            // size of one node table
+    unsigned long long oct_tables;   // byte k: the table for rays of direction octant k
     RtLight light;
 };
 
@@ -619,7 +621,18 @@ template <bool STATS, class B>
 __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool active0, double far, B &best, Ctr<STATS> &ctr) {
     const int end = S.n_nodes;
     if (end <= 0) return;
-    NodeRaw raw = node_fetch<true>(S.nodes, 0);
+    // The node table whose sibling lists are in front-to-back order for most rays of the wave: per axis, the sign
+    // that the majority of the participating lanes' directions have.  Any table gives the same result (the closest
+    // hit does not depend on the order objects are met in); this one finds it earliest.
+    NodeP nodes = S.nodes;
+    if constexpr (!STATS && !B::every) {
+        const unsigned half = (unsigned)__popcll(__ballot(active0)) >> 1;
+        const unsigned oct = ((unsigned)__popcll(__ballot(active0 && d.x < 0.0)) > half ? 1u : 0u) | ((unsigned)__popcll(__ballot(active0 && d.y < 0.0)) > half ? 2u : 0u) |
+                             ((unsigned)__popcll(__ballot(active0 && d.z < 0.0)) > half ? 4u : 0u);
+        const unsigned table = (unsigned)(S.oct_tables >> (8u * oct)) & 0xffu;
+        nodes = (NodeP)((const char RT_CONSTANT_AS *)S.nodes + (size_t)table * S.table_bytes);
+    }
+    NodeRaw raw = node_fetch<true>(nodes, 0);
     asm volatile("" ::"s"(raw.b[8]));  // as in trace_flat
     ParkedRays parked;
     parked.lds = ray_stack_lds + S.park_base + (threadIdx.x & 63u);
@@ -673,7 +686,7 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
         // than not sends the traversal to `skip` (the table has one spare record at its end).
         const int guess = (kind == RT_SKIPBOX && !STATS && !B::every) ? w.skip : i + 1;
         asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(ld.x), "+v"(ld.y), "+v"(ld.z));  // the transform is complete
-        NodeRaw nraw = node_fetch<true>(S.nodes, guess);
+        NodeRaw nraw = node_fetch<true>(nodes, guess);
         int ni = i + 1;
         RT_NODE_VISIT(kind == RT_SKIPBOX ? 0 : kind == RT_GROUP ? 1 : 2);
         if (kind == RT_SKIPBOX) {
@@ -715,7 +728,7 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
             }
         }
         if (ni != guess) {
-            nraw = node_fetch<true>(S.nodes, ni);  // guessed wrong: fetch the record wanted
+            nraw = node_fetch<true>(nodes, ni);  // guessed wrong: fetch the record wanted
             RT_NODE_VISIT(3);
         }
         pin(best);  // as in trace_flat
@@ -1120,6 +1133,8 @@ __device__ __forceinline__ SceneK scene_k(const DeviceScene &d, int max_depth) {
     S.max_depth = max_depth;
     S.stack_base = (unsigned)uniform((int)(threadIdx.x >> 6)) * LDS_WAVE_DOUBLES<NEST, RADIANCE>;
     S.park_base = S.stack_base + (RADIANCE ? LDS_LEVELS * 8 * 64 : 0);
+    S.table_bytes = d.table_records * (unsigned)sizeof(RtNode);
+    S.oct_tables = d.oct_tables;
     S.light = d.light;
     return S;
 }

@@ -143,6 +143,10 @@ struct Builder {
     std::vector<ConeDirs> cones;  // per object, in its parent's space
     std::vector<std::vector<uint32_t>> kids;
     std::vector<int32_t> leaf_id;  // per object: its number among the leaves in the reference's (depth-first) order
+    std::vector<RtNode> *nodes = nullptr;  // the table being emitted
+    bool counting = true;   // emitting the first table: the one whose groups and range-skip nodes are counted
+    bool ordered = false;   // lists are emitted in spatial order with range-skip nodes (false: a world without groups
+                            // and with a short list keeps the reference's order and gets the lean kernels)
 
     bool fail(int c, const char *fmt, unsigned idx) {
         char buf[160];
@@ -193,13 +197,13 @@ struct Builder {
         return true;
     }
 
-    // A conservative box around siblings list[a..b), or false when there is none worth testing.
-    bool skip_box(const std::vector<uint32_t> &list, size_t a, size_t b, double box[6], ConeDirs &dirs) const {
+    // A conservative box around the siblings `members`, or false when there is none worth testing.
+    bool skip_box(const std::vector<uint32_t> &members, double box[6], ConeDirs &dirs) const {
         Bounds u = Bounds::empty();
         dirs = ConeDirs{};
-        for (size_t k = a; k < b; ++k) {
-            u = u.merge(in_parent[list[k]]);
-            dirs.merge(cones[list[k]]);
+        for (uint32_t k : members) {
+            u = u.merge(in_parent[k]);
+            dirs.merge(cones[k]);
         }
         if (dirs.any && !dirs.ok) return false;
         const double lo[3] = {u.min.x, u.min.y, u.min.z}, hi[3] = {u.max.x, u.max.y, u.max.z};
@@ -225,134 +229,162 @@ struct Builder {
         }
         head.leaf = -1;
         for (int i = 0; i < 6; ++i) head.a[i] = box[i];
-        out.nodes.push_back(head);
-        out.n_skip_nodes++;
+        nodes->push_back(head);
+        if (counting) out.n_skip_nodes++;
     }
 
-    // Total surface area of the boxes emit_range() would put round the ranges of list[a..b) (all members bounded):
-    // a measure of how often rays will have to look inside them.
-    double boxes_area(const std::vector<uint32_t> &list, size_t a, size_t b, bool whole_list) const {
-        const size_t n = b - a;
-        if (n <= (whole_list ? SKIP_MIN_LIST : SKIP_RUN)) return 0.0;
-        const size_t parts = n > 4 * SKIP_RUN ? 4 : 2;
-        double total = 0.0;
-        for (size_t p = 0; p < parts; ++p) {
-            const size_t pa = a + n * p / parts, pb = a + n * (p + 1) / parts;
-            if (pb - pa >= 2) {
-                Bounds u = Bounds::empty();
-                for (size_t k = pa; k < pb; ++k) u = u.merge(in_parent[list[k]]);
-                const double dx = u.max.x - u.min.x, dy = u.max.y - u.min.y, dz = u.max.z - u.min.z;
-                total += dx * dy + dy * dz + dz * dx;
-            }
-            total += boxes_area(list, pa, pb, false);
+    // The order tree of a sibling list: the members with finite bounds, split at the median of their centres along
+    // the axis the centres spread most, recursively down to single members.  A table for rays travelling towards
+    // +axis lists the low half of every split first, one for rays travelling towards -axis the high half: whatever
+    // a ray meets first in space it then also meets first in the table, its closest hit is found early, and the
+    // range-skip boxes behind that hit are rejected by distance.  Members without finite bounds (planes, unlimited
+    // cylinders and cones: no box can hold them) stay in front, in the reference's order.
+    struct OrderNode {
+        int32_t left = -1, right = -1;
+        uint32_t member = 0, count = 0;
+        int axis = 0;
+    };
+    struct ListLayout {
+        std::vector<uint32_t> unbounded;
+        std::vector<OrderNode> tree;
+        int32_t root = -1;
+    };
+    std::vector<ListLayout> layouts;  // per object (groups: their children); the last one is the world's own list
+
+    bool finite_bounds(uint32_t k) const {
+        const Bounds &bb = in_parent[k];
+        return std::isfinite(bb.min.x) && std::isfinite(bb.min.y) && std::isfinite(bb.min.z) && std::isfinite(bb.max.x) &&
+               std::isfinite(bb.max.y) && std::isfinite(bb.max.z);
+    }
+    double centre(uint32_t k, int axis) const {
+        const Bounds &bb = in_parent[k];
+        return axis == 0 ? bb.min.x + bb.max.x : axis == 1 ? bb.min.y + bb.max.y : bb.min.z + bb.max.z;
+    }
+    int32_t build_tree(ListLayout &L, std::vector<uint32_t>::iterator lo, std::vector<uint32_t>::iterator hi) {
+        const int32_t at = (int32_t)L.tree.size();
+        L.tree.emplace_back();
+        const size_t n = (size_t)(hi - lo);
+        L.tree[(size_t)at].count = (uint32_t)n;
+        if (n == 1) {
+            L.tree[(size_t)at].member = *lo;
+            return at;
         }
-        return total;
-    }
-
-    // Siblings of a long list, reordered so that every range emit_range() will box is spatially compact: members
-    // without finite bounds first (no box can hold them), then a median split along the longest axis of the centres,
-    // recursively down to the length of a run.  The closest-hit update of the kernels that walk such tables does not
-    // depend on the order objects are met in (Closest<true> in rt_device.hip), and neither do the counters; but that
-    // update costs a little per candidate, so the new order is only taken when it
-    // shrinks the boxes' total area by a quarter (the twenty spheres of a chapter_14 group: by 40-50 %; 25 random objects in a cell
-    // of the generated scene: by 0-20 %, which was measured to buy nothing).
-    void spatial_order(std::vector<uint32_t> &list) {
-        auto finite = [&](uint32_t k) {
-            const Bounds &bb = in_parent[k];
-            return std::isfinite(bb.min.x) && std::isfinite(bb.min.y) && std::isfinite(bb.min.z) && std::isfinite(bb.max.x) &&
-                   std::isfinite(bb.max.y) && std::isfinite(bb.max.z);
-        };
-        std::vector<uint32_t> sorted = list;
-        const auto first_finite = std::stable_partition(sorted.begin(), sorted.end(), [&](uint32_t k) { return !finite(k); });
-        std::vector<uint32_t> bounded_in_order(first_finite, sorted.end());  // the reference's order, unbounded ones taken out
-        auto centre = [&](uint32_t k, int axis) {
-            const Bounds &bb = in_parent[k];
-            return axis == 0 ? bb.min.x + bb.max.x : axis == 1 ? bb.min.y + bb.max.y : bb.min.z + bb.max.z;
-        };
-        struct Split {
-            decltype(centre) &centre;
-            void run(std::vector<uint32_t>::iterator lo, std::vector<uint32_t>::iterator hi) const {
-                const size_t n = (size_t)(hi - lo);
-                if (n <= SKIP_RUN) {
-                    std::sort(lo, hi);  // inside a run: the reference's order
-                    return;
-                }
-                double cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-                for (auto it = lo; it != hi; ++it)
-                    for (int a = 0; a < 3; ++a) {
-                        cmin[a] = std::fmin(cmin[a], centre(*it, a));
-                        cmax[a] = std::fmax(cmax[a], centre(*it, a));
-                    }
-                int axis = 0;
-                for (int a = 1; a < 3; ++a)
-                    if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
-                const auto mid = lo + (std::ptrdiff_t)(n / 2);
-                std::nth_element(lo, mid, hi, [&](uint32_t x, uint32_t y) {
-                    const double cx = centre(x, axis), cy = centre(y, axis);
-                    return cx < cy || (cx == cy && x < y);
-                });
-                run(lo, mid);
-                run(mid, hi);
+        double cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (auto it = lo; it != hi; ++it)
+            for (int a = 0; a < 3; ++a) {
+                cmin[a] = std::fmin(cmin[a], centre(*it, a));
+                cmax[a] = std::fmax(cmax[a], centre(*it, a));
             }
-        };
-        Split{centre}.run(first_finite, sorted.end());
-        if (sorted == list) return;
-        const std::vector<uint32_t> bounded_sorted(first_finite, sorted.end());
-        const double before = boxes_area(bounded_in_order, 0, bounded_in_order.size(), true);
-        const double after = boxes_area(bounded_sorted, 0, bounded_sorted.size(), true);
-        if (after < 0.75 * before) {
-            list.swap(sorted);
-            out.reordered = true;
+        int axis = 0;
+        for (int a = 1; a < 3; ++a)
+            if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+        const auto mid = lo + (std::ptrdiff_t)(n / 2);
+        std::nth_element(lo, mid, hi, [&](uint32_t x, uint32_t y) {
+            const double cx = centre(x, axis), cy = centre(y, axis);
+            return cx < cy || (cx == cy && x < y);
+        });
+        const int32_t l = build_tree(L, lo, mid), r = build_tree(L, mid, hi);
+        OrderNode &t = L.tree[(size_t)at];
+        t.axis = axis;
+        t.left = l;
+        t.right = r;
+        return at;
+    }
+    void build_layout(ListLayout &L, const std::vector<uint32_t> &list) {
+        std::vector<uint32_t> bounded;
+        for (uint32_t k : list) (ordered && finite_bounds(k) ? bounded : L.unbounded).push_back(k);
+        if (!bounded.empty()) L.root = build_tree(L, bounded.begin(), bounded.end());
+        if (bounded.size() >= 2) out.reordered = true;
+    }
+    // The two halves of a split in the order a table for octant `oct` lists them (bit a of oct: rays travel towards -a)
+    static void halves(const OrderNode &t, unsigned oct, int32_t &first, int32_t &second) {
+        const bool flip = ((oct >> t.axis) & 1u) != 0;
+        first = flip ? t.right : t.left;
+        second = flip ? t.left : t.right;
+    }
+    void collect(const ListLayout &L, int32_t node, unsigned oct, std::vector<uint32_t> &members) const {
+        const OrderNode &t = L.tree[(size_t)node];
+        if (t.count == 1) {
+            members.push_back(t.member);
+            return;
         }
+        int32_t a, b;
+        halves(t, oct, a, b);
+        collect(L, a, oct, members);
+        collect(L, b, oct, members);
     }
 
-    // Pass 2: emits siblings list[a..b) in order, wrapping sub-ranges of long lists in range-skip nodes.
-    bool emit_range(const std::vector<uint32_t> &list, size_t a, size_t b, uint32_t depth, bool whole_list = false) {
-        const size_t n = b - a;
+    // Emits the members below `node` of a list's order tree, wrapping sub-ranges of long lists in range-skip nodes:
+    // lists longer than SKIP_MIN_LIST are cut in two or (above 4 runs) four parts, recursively, until a part has at
+    // most SKIP_RUN members; every part of two or more members gets a node.
+    bool emit_tree(const ListLayout &L, int32_t node, uint32_t depth, unsigned oct, bool whole_list) {
+        const OrderNode &t = L.tree[(size_t)node];
+        const size_t n = t.count;
         if (n <= (whole_list ? SKIP_MIN_LIST : SKIP_RUN)) {
-            for (size_t k = a; k < b; ++k) {
+            std::vector<uint32_t> members;
+            collect(L, node, oct, members);
+            for (uint32_t m : members) {
                 // A member whose own test is expensive next to a box test (a group: ray transform + six divisions;
-                // cube, cylinder, cone: ray transform + a long intersection routine) gets a node of its own in
-                // front -- except in the short lists of a scene without groups, which keeps the lean kernel.
-                const int kind = world.objects[list[k]].kind;
+                // cube, cylinder, cone: ray transform + a long intersection routine) gets a node of its own in front.
+                const int kind = world.objects[m].kind;
                 double box[6];
                 ConeDirs dirs;
-                const bool wrap = (!whole_list || out.max_nesting >= 1) && kind != RT_SPHERE && kind != RT_PLANE && skip_box(list, k, k + 1, box, dirs);
-                const size_t ni = out.nodes.size();
+                const bool wrap = ordered && kind != RT_SPHERE && kind != RT_PLANE && skip_box({m}, box, dirs);
+                const size_t ni = nodes->size();
                 if (wrap) push_skip(box, dirs, depth);
-                if (!emit(list[k], depth)) return false;
-                if (wrap) out.nodes[ni].skip = (int32_t)out.nodes.size();
+                if (!emit(m, depth, oct)) return false;
+                if (wrap) (*nodes)[ni].skip = (int32_t)nodes->size();
             }
             return true;
         }
-        const size_t parts = n > 4 * SKIP_RUN ? 4 : 2;
-        for (size_t p = 0; p < parts; ++p) {
-            const size_t pa = a + n * p / parts, pb = a + n * (p + 1) / parts;
+        int32_t half[2];
+        halves(t, oct, half[0], half[1]);
+        std::vector<int32_t> parts;
+        for (int32_t h : half) {
+            const OrderNode &c = L.tree[(size_t)h];
+            if (n > 4 * SKIP_RUN && c.count >= 2) {
+                int32_t a, b;
+                halves(c, oct, a, b);
+                parts.push_back(a);
+                parts.push_back(b);
+            } else {
+                parts.push_back(h);
+            }
+        }
+        for (int32_t part : parts) {
+            std::vector<uint32_t> members;
+            collect(L, part, oct, members);
             double box[6];
             ConeDirs dirs;
-            if (pb - pa >= 2 && skip_box(list, pa, pb, box, dirs)) {
-                const size_t ni = out.nodes.size();
+            if (members.size() >= 2 && skip_box(members, box, dirs)) {
+                const size_t ni = nodes->size();
                 push_skip(box, dirs, depth);
-                if (!emit_range(list, pa, pb, depth)) return false;
-                out.nodes[ni].skip = (int32_t)out.nodes.size();
-            } else if (!emit_range(list, pa, pb, depth)) {
+                if (!emit_tree(L, part, depth, oct, false)) return false;
+                (*nodes)[ni].skip = (int32_t)nodes->size();
+            } else if (!emit_tree(L, part, depth, oct, false)) {
                 return false;
             }
         }
         return true;
     }
 
+    bool emit_list(const ListLayout &L, uint32_t depth, unsigned oct) {
+        for (uint32_t m : L.unbounded)
+            if (!emit(m, depth, oct)) return false;
+        return L.root < 0 || emit_tree(L, L.root, depth, oct, true);
+    }
+
     // Appends object `idx` and its subtree.
-    bool emit(uint32_t idx, uint32_t depth) {
+    bool emit(uint32_t idx, uint32_t depth, unsigned oct) {
         const rt_object_desc &o = world.objects[idx];
         Matrix4 T = Matrix4::from_array(o.transformation);
         auto Tinv = T.inverse();
         if (!Tinv) return fail(RT_ERR_NOT_INVERTIBLE, o.kind == RT_GROUP ? "group transformation should be invertible (object #%u)"
                                                                          : "shape transformation should be invertible (object #%u)", idx);
-        size_t ni = out.nodes.size();
-        out.nodes.emplace_back();
+        size_t ni = nodes->size();
+        nodes->emplace_back();
         {
-            RtNode &n = out.nodes[ni];
+            RtNode &n = (*nodes)[ni];
             std::memset(&n, 0, sizeof n);
             rows3(*Tinv, n.inv);
             n.xform = classify(n.inv);
@@ -361,14 +393,13 @@ struct Builder {
         }
 
         if (o.kind == RT_GROUP) {
-            out.n_groups++;
-            if (kids[idx].size() > SKIP_MIN_LIST) spatial_order(kids[idx]);
-            if (!emit_range(kids[idx], 0, kids[idx].size(), depth + 1, true)) return false;
+            if (counting) out.n_groups++;
+            if (!emit_list(layouts[idx], depth + 1, oct)) return false;
             const Bounds &gb = own[idx];
-            RtNode &n = out.nodes[ni];
+            RtNode &n = (*nodes)[ni];
             n.a[0] = gb.min.x; n.a[1] = gb.min.y; n.a[2] = gb.min.z;
             n.a[3] = gb.max.x; n.a[4] = gb.max.y; n.a[5] = gb.max.z;
-            n.skip = (int32_t)out.nodes.size();
+            n.skip = (int32_t)nodes->size();
             return true;
         }
 
@@ -395,7 +426,7 @@ struct Builder {
             for (int i = 0; i < 3; ++i) { s.pat_a[i] = m.pattern.color_a[i]; s.pat_b[i] = m.pattern.color_b[i]; }
             s.pattern_kind = m.pattern.kind;
         }
-        RtNode &n = out.nodes[ni];
+        RtNode &n = (*nodes)[ni];
         n.a[0] = o.minimum;
         n.a[1] = o.maximum;
         n.leaf = leaf_id[idx];
@@ -413,7 +444,6 @@ int flatten_world(const rt_world_desc &world, FlatScene &out, std::string &err) 
         err = "rt_world_desc.objects is NULL";
         return RT_ERR_INVALID_ARGUMENT;
     }
-    out.nodes.reserve(world.n_objects + world.n_objects / 2);
     Builder b(world, out, err);
     b.own.resize(world.n_objects);
     b.in_parent.resize(world.n_objects);
@@ -436,8 +466,36 @@ int flatten_world(const rt_world_desc &world, FlatScene &out, std::string &err) 
         return RT_ERR_UNSUPPORTED;
     }
     out.surfaces.resize(out.n_leaves);
-    if (top.size() > SKIP_MIN_LIST) b.spatial_order(top);
-    if (!b.emit_range(top, 0, top.size(), 0, true)) return b.code;
+    bool any_group = false;
+    for (uint32_t k = 0; k < world.n_objects; ++k) any_group = any_group || world.objects[k].kind == RT_GROUP;
+    b.ordered = any_group || top.size() > SKIP_MIN_LIST;
+    b.layouts.resize((size_t)world.n_objects + 1);
+    for (uint32_t k = 0; k < world.n_objects; ++k)
+        if (world.objects[k].kind == RT_GROUP) b.build_layout(b.layouts[k], b.kids[k]);
+    b.build_layout(b.layouts[world.n_objects], top);
+    // One table per octant of ray directions (an ordered world), or the one table in the reference's order.  Octants
+    // whose tables come out identical (no split along some axis anywhere in the world) share one.
+    std::vector<std::vector<RtNode>> tables;
+    const unsigned n_oct = b.ordered ? 8u : 1u;
+    for (unsigned oct = 0; oct < n_oct; ++oct) {
+        std::vector<RtNode> t;
+        t.reserve(world.n_objects + world.n_objects / 2 + 1);
+        b.nodes = &t;
+        b.counting = oct == 0;
+        if (!b.emit_list(b.layouts[world.n_objects], 0, oct)) return b.code;
+        t.emplace_back();  // one inert record past the end: the traversal fetches record i+1 while it works on record i
+        std::memset(&t.back(), 0, sizeof(RtNode));
+        size_t same = tables.size();
+        for (size_t k = 0; k < tables.size(); ++k)
+            if (tables[k].size() == t.size() && std::memcmp(tables[k].data(), t.data(), t.size() * sizeof(RtNode)) == 0) same = k;
+        out.oct_table[oct] = (uint8_t)same;
+        if (same == tables.size()) tables.push_back(std::move(t));
+    }
+    for (unsigned oct = n_oct; oct < 8; ++oct) out.oct_table[oct] = 0;
+    out.table_records = (uint32_t)tables[0].size();
+    out.n_tables = (uint32_t)tables.size();
+    out.nodes.clear();
+    for (const auto &t : tables) out.nodes.insert(out.nodes.end(), t.begin(), t.end());
     out.light.has_light = world.has_light ? 1 : 0;
     for (int i = 0; i < 3; ++i) {
         out.light.position[i] = world.light_position[i];

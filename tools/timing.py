@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): phase timing of the render kernel from a library built with -DRT_TIMING.
 
-    RT_AMD_LIB=tools/bin/timing.so python tools/timing.py [scene.toml] [width] [height]
+    RT_AMD_LIB=ab/timing.so python tools/timing.py [scene.toml] [width] [height]
 """
 import ctypes
 import os
