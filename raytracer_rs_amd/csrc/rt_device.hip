@@ -930,8 +930,17 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
     double stk[STACK_MAX - LDS_LEVELS][7];
     int stk_rem[STACK_MAX - LDS_LEVELS];
     int sp = 0;
+    // The kernels for scenes with groups keep no register copy of the newest entry: their traversal needs the fifteen
+    // registers more than a pop needs to be free of a memory round trip (with the copy: 21 spilled VGPRs, 1-2 % slower).
+    constexpr bool REG_TOP = NEST == 0;
     auto push = [&](V3 po, V3 pd, double pw, int prem) {
-        if (nx_rem >= 0) {
+        if constexpr (!REG_TOP) {
+            nx_o = po;
+            nx_d = pd;
+            nx_w = pw;
+            nx_rem = prem;
+        }
+        if (!REG_TOP || nx_rem >= 0) {
             if (sp < LDS_LEVELS) {
                 double *e = lds + sp * (8 * 64);
                 e[0 * 64] = nx_o.x; e[1 * 64] = nx_o.y; e[2 * 64] = nx_o.z;
@@ -947,10 +956,12 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
             }
             sp++;
         }
-        nx_o = po;
-        nx_d = pd;
-        nx_w = pw;
-        nx_rem = prem;
+        if constexpr (REG_TOP) {
+            nx_o = po;
+            nx_d = pd;
+            nx_w = pw;
+            nx_rem = prem;
+        }
     };
 
     const V3 light_pos = mk(S.light.position[0], S.light.position[1], S.light.position[2]);
@@ -1064,13 +1075,16 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
         }
         RT_TIC(tm3);
         // the lane's next ray
-        have = nx_rem >= 0;
+        if constexpr (!REG_TOP) nx_rem = -1;
+        have = REG_TOP ? nx_rem >= 0 : sp > 0;
         if (have) {
-            ro = nx_o;
-            rd = nx_d;
-            w = nx_w;
-            remaining = nx_rem;
-            nx_rem = -1;
+            if constexpr (REG_TOP) {
+                ro = nx_o;
+                rd = nx_d;
+                w = nx_w;
+                remaining = nx_rem;
+                nx_rem = -1;
+            }
             if (sp > 0) {
                 sp--;
                 if (sp < LDS_LEVELS) {
@@ -1086,6 +1100,13 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
                     nx_w = stk[d][6];
                     nx_rem = stk_rem[d];
                 }
+            }
+            if constexpr (!REG_TOP) {
+                ro = nx_o;
+                rd = nx_d;
+                w = nx_w;
+                remaining = nx_rem;
+                nx_rem = -1;
             }
         }
 #ifdef RT_TIMING
@@ -1157,6 +1178,7 @@ __device__ __forceinline__ unsigned quantize_value(double v) {
 //   [256 + 1*n, 256 + 2*n)   cost estimate per tile
 //   [256 + 2*n, 256 + 3*n)   class per tile
 enum { TILE_CLASSES = 128, TILE_HEADER = 2 * TILE_CLASSES };
+enum { RENDER_BLOCK = 64 };  // threads per workgroup of render_kernel
 __device__ __forceinline__ unsigned image_row(const RowMap &rows, unsigned r) {
     return rows.row_begin + (r / rows.band_rows) * rows.band_pitch + (r % rows.band_rows);
 }
@@ -1303,8 +1325,9 @@ __global__ __launch_bounds__(ORDER_BLOCK) void order_scatter_kernel(RowMap rows,
 }
 
 // Camera::render (rendering/camera.rs:56-67) for the rows of `rows`: one wave per 8x8 pixel tile.
+// Launched with one wave per workgroup (RENDER_BLOCK); four waves per SIMD: a budget of 128 VGPRs per lane.
 template <bool STATS, int NEST, bool TIES>
-__global__ __launch_bounds__(256, 4) void render_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth,
+__global__ __launch_bounds__(RENDER_BLOCK, 4) void render_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth,
                                                      double *__restrict__ rgb, unsigned long long *counters) {
     const unsigned lane = threadIdx.x & 63;
     unsigned tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1659,7 +1682,7 @@ hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, co
     }
     // One wave per workgroup: a finished wave's slot is refilled at once, without waiting for three more.
     const dim3 grid(rows.n_tiles);
-    const unsigned block = 64;
+    const unsigned block = RENDER_BLOCK;
     if (counters)
         launch_render_nest<true>(scene.max_nesting, grid, block, stream, scene, camera, rows, max_depth, rgb, counters);
     else

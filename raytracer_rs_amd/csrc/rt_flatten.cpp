@@ -58,8 +58,14 @@ Bounds leaf_bounds(const rt_object_desc &o) {
 // Range-skip nodes (see RT_SKIPBOX in rt_device_types.h): sibling lists longer than SKIP_MIN_LIST are cut into
 // runs, recursively, until a run has at most SKIP_RUN members; every run of two or more bounded siblings gets a node.
 // Short lists are left alone: a test per node is cheaper than the wider record fetch and the extra branches.
-constexpr size_t SKIP_MIN_LIST = 12;
-constexpr size_t SKIP_RUN = 6;
+static size_t env_size(const char *name, size_t fallback) {
+    const char *e = std::getenv(name);
+    return e && *e ? (size_t)std::strtoul(e, nullptr, 10) : fallback;
+}
+// (developer overrides for tuning runs: RT_SKIP_MIN_LIST, RT_SKIP_RUN, RT_SKIP_WIDE)
+static const size_t SKIP_MIN_LIST = env_size("RT_SKIP_MIN_LIST", 12);
+static const size_t SKIP_RUN = env_size("RT_SKIP_RUN", 6);
+static const size_t SKIP_WIDE = env_size("RT_SKIP_WIDE", 24);  // lists longer than this are cut in four parts at a time, not two
 
 // The directions for which some cone below a node takes the shortcut of cones.rs:66-78: with a = dx^2 - dy^2 + dz^2
 // of the ray in the cone's space below EPSILON, the reference accepts t = -c / (2 b) -- a point that need not lie on
@@ -342,7 +348,7 @@ struct Builder {
         std::vector<int32_t> parts;
         for (int32_t h : half) {
             const OrderNode &c = L.tree[(size_t)h];
-            if (n > 4 * SKIP_RUN && c.count >= 2) {
+            if (n > SKIP_WIDE && c.count >= 2) {
                 int32_t a, b;
                 halves(c, oct, a, b);
                 parts.push_back(a);
