@@ -155,9 +155,9 @@ def main() -> None:
             bg.begin_render(k)
         # with 8-bit collection the render kernel quantises its own output (RT_RENDER_QUANTIZED)
         if not multi:
-            st = scene.render_device(cam, target.data_ptr(), None, 0, stream, stats, timed, u8)
+            st = scene.render_device(cam, target.data_ptr(), None, None, stream, stats, timed, u8)
         else:
-            st = scene.render_device_bands(cam, target.data_ptr(), BAND_ROWS, rank, world_size, 0, stream, stats, timed, u8)
+            st = scene.render_device_bands(cam, target.data_ptr(), BAND_ROWS, rank, world_size, None, stream, stats, timed, u8)
         return st
 
     def step(k: int):
@@ -244,7 +244,7 @@ def main() -> None:
 
     if args.check and rank == 0:
         whole = torch.zeros(H * W * 3, dtype=torch.float64, device=dev)
-        scene.render_device(cam, whole.data_ptr(), None, 0, stream, False)
+        scene.render_device(cam, whole.data_ptr(), None, None, stream, False)
         if u8:
             q = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
             rt.quantize_device(whole.data_ptr(), whole.numel(), q.data_ptr(), stream)

@@ -16,7 +16,11 @@
  *     is followed by its `n_children` children, each of which may itself be a group.
  *   - all arithmetic on the path is IEEE f64 without multiply-add contraction, in the reference's operation order.
  *   - the caller owns every output buffer; handles are opaque; a handle is bound to the HIP device it was created
- *     on and serves one call at a time.
+ *     on and serves ONE CALL AT A TIME: a scene handle owns device scratch (tile order, counters, timing events, the
+ *     staging pipeline of rt_render) that every render through it rewrites, whatever the `const` in the signatures
+ *     suggests.  Calls from several host threads on one handle, and asynchronous launches through one handle that
+ *     may overlap on the device (different streams), must be serialised by the caller; different handles -- also of
+ *     the same world on the same device -- are independent.
  *   - there is no CPU fallback: without a HIP device every rendering entry point fails with RT_ERR_NO_DEVICE.
  */
 #ifndef RAYTRACER_RS_AMD_H
@@ -115,7 +119,9 @@ typedef struct rt_stats {
 
 typedef struct rt_render_opts {
     uint32_t row_begin, row_end; /* rows [row_begin, row_end) of the frame; both 0 = the whole frame */
-    int32_t max_depth;           /* recursion budget per pixel; 0 = RT_DEFAULT_DEPTH */
+    int32_t max_depth;           /* recursion budget per pixel (world.rs:117 `remaining`).  0 = RT_DEFAULT_DEPTH, so that
+                                    zeroed options mean the reference's behaviour; a budget of zero itself (no
+                                    reflection or refraction rays at all) is max_depth = 0 with RT_RENDER_EXACT_DEPTH */
     int32_t collect_stats;       /* non-zero: run the counting variant of the kernel and fill rt_stats */
     void *stream;                /* hipStream_t for rt_render_device; NULL = the null stream */
     /* Row-band sharding (one frame over several GPUs): when band_rows > 0 the frame is cut into bands of band_rows
@@ -130,6 +136,9 @@ typedef struct rt_render_opts {
  * canvas quantiser (rendering/canvas.rs:123-130) applied by the render kernel itself; the same bytes as rendering
  * doubles and running rt_canvas_quantize_device over them, without the f64 frame ever being written. */
 #define RT_RENDER_QUANTIZED 2u
+/* rt_render, rt_render_device: max_depth is the budget exactly as given, 0 included (without this flag 0 selects
+ * RT_DEFAULT_DEPTH). */
+#define RT_RENDER_EXACT_DEPTH 4u
 
 typedef struct rt_scene_info {
     uint32_t n_objects, n_leaves, n_groups, max_nesting;
@@ -164,7 +173,9 @@ void rt_scene_destroy(rt_scene *scene);
 int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out);
 
 /* Camera::render (rendering/camera.rs:56-67): writes rows [row_begin,row_end) of the frame into the host buffer
- * `rgb` (which holds the WHOLE frame: hsize*vsize*3 doubles; rows outside the range are left untouched). */
+ * `rgb` (which holds the WHOLE frame: hsize*vsize*3 doubles; rows outside the range are left untouched).  The handle
+ * keeps a device frame and pinned staging memory of the size of the largest frame rendered through it, so that
+ * kernels, the transfer over PCIe and the copy into `rgb` overlap. */
 int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts, double *rgb,
               rt_stats *stats);
 /* The same on device memory, asynchronously on opts->stream: `rgb_device` receives only the rows rendered, packed:

@@ -22,6 +22,7 @@ MAX_GROUP_NESTING = 16
 DEFAULT_DEPTH = 5
 RENDER_TIMED = 1
 RENDER_QUANTIZED = 2
+RENDER_EXACT_DEPTH = 4
 MAX_DEPTH = 8
 NOALLOC_MAX_TILES = 524288
 

@@ -272,6 +272,13 @@ def _flatten_objects(objects: Sequence[Object], out: List[L.ObjectDesc], index: 
             _flatten_objects(obj.children, out, index)
 
 
+def _set_depth(opts: "L.RenderOpts", max_depth: Optional[int]) -> None:
+    """None = the reference's DEFAULT_MAX_*_DEPTH (world.rs:11-12); a number is the budget exactly, 0 included."""
+    if max_depth is not None:
+        opts.max_depth = int(max_depth)
+        opts.flags |= L.RENDER_EXACT_DEPTH
+
+
 class Scene:
     """A World resident on one GPU (`rt_scene`)."""
 
@@ -296,7 +303,7 @@ class Scene:
         L.check(L.lib().rt_scene_get_info(self._h, C.byref(i)))
         return i
 
-    def render(self, camera: "Camera", rows: Optional[Tuple[int, int]] = None, max_depth: int = 0,
+    def render(self, camera: "Camera", rows: Optional[Tuple[int, int]] = None, max_depth: Optional[int] = None,
                stats: bool = False, out: Optional[np.ndarray] = None,
                bands: Optional[Tuple[int, int, int]] = None):
         """rt_render into a host array [vsize, hsize, 3]; returns (array, Stats).  `rows` = (begin, end) restricts
@@ -309,7 +316,7 @@ class Scene:
             opts.band_rows, opts.band_first, opts.band_step = bands
         if rows is not None:
             opts.row_begin, opts.row_end = rows
-        opts.max_depth = max_depth
+        _set_depth(opts, max_depth)
         opts.collect_stats = int(stats)
         st = L.Stats()
         L.check(L.lib().rt_render(self._h, C.byref(cd), C.byref(opts), out.ctypes.data_as(C.POINTER(C.c_double)),
@@ -324,7 +331,7 @@ class Scene:
         return a.value, b.value
 
     def render_device(self, camera: "Camera", device_ptr: int, rows: Optional[Tuple[int, int]] = None,
-                      max_depth: int = 0, stream: int = 0, stats: bool = False, timed: bool = False,
+                      max_depth: Optional[int] = None, stream: int = 0, stats: bool = False, timed: bool = False,
                       quantized: bool = False) -> Optional[L.Stats]:
         """rt_render_device: asynchronous launch on `stream` into device memory at `device_ptr`
         ((row_end-row_begin)*hsize*3 doubles)."""
@@ -332,32 +339,32 @@ class Scene:
         opts = L.RenderOpts()
         if rows is not None:
             opts.row_begin, opts.row_end = rows
-        opts.max_depth = max_depth
         opts.collect_stats = int(stats)
         opts.stream = C.c_void_p(stream)
         opts.flags = (L.RENDER_TIMED if timed else 0) | (L.RENDER_QUANTIZED if quantized else 0)
+        _set_depth(opts, max_depth)
         st = L.Stats()
         L.check(L.lib().rt_render_device(self._h, C.byref(cd), C.byref(opts), C.c_void_p(device_ptr), C.byref(st)))
         return st if stats else None
 
     def render_device_bands(self, camera: "Camera", device_ptr: int, band_rows: int, band_first: int, band_step: int,
-                            max_depth: int = 0, stream: int = 0, stats: bool = False, timed: bool = False,
+                            max_depth: Optional[int] = None, stream: int = 0, stats: bool = False, timed: bool = False,
                             quantized: bool = False) -> Optional[L.Stats]:
         """rt_render_device restricted to bands band_first, band_first+band_step, ... of band_rows rows each; the
         bands are written one after another at `device_ptr`."""
         cd = camera._desc()
         opts = L.RenderOpts()
         opts.band_rows, opts.band_first, opts.band_step = band_rows, band_first, band_step
-        opts.max_depth = max_depth
         opts.collect_stats = int(stats)
         opts.stream = C.c_void_p(stream)
         opts.flags = (L.RENDER_TIMED if timed else 0) | (L.RENDER_QUANTIZED if quantized else 0)
+        _set_depth(opts, max_depth)
         st = L.Stats()
         L.check(L.lib().rt_render_device(self._h, C.byref(cd), C.byref(opts), C.c_void_p(device_ptr), C.byref(st)))
         return st if stats else None
 
     def render_device_noalloc(self, camera: "Camera", device_ptr: int, rows: Optional[Tuple[int, int]] = None,
-                              bands: Optional[Tuple[int, int, int]] = None, max_depth: int = 0, stream: int = 0,
+                              bands: Optional[Tuple[int, int, int]] = None, max_depth: Optional[int] = None, stream: int = 0,
                               quantized: bool = False) -> None:
         """rt_render_device_noalloc: rt_render_device without any allocation (its tile-ordering scratch is a static
         device array); at most NOALLOC_MAX_TILES 8x8-pixel tiles per call."""
@@ -367,9 +374,9 @@ class Scene:
             opts.row_begin, opts.row_end = rows
         if bands is not None:
             opts.band_rows, opts.band_first, opts.band_step = bands
-        opts.max_depth = max_depth
         opts.stream = C.c_void_p(stream)
         opts.flags = L.RENDER_QUANTIZED if quantized else 0
+        _set_depth(opts, max_depth)
         L.check(L.lib().rt_render_device_noalloc(self._h, C.byref(cd), C.byref(opts), C.c_void_p(device_ptr)))
 
     def color_at(self, rays: np.ndarray, remaining: int = L.DEFAULT_DEPTH, stats: bool = False):

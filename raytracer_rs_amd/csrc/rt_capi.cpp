@@ -2,6 +2,7 @@
 // rendering entry point needs a HIP device and fails with RT_ERR_NO_DEVICE / RT_ERR_HIP otherwise.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <cstddef>
 #include <cmath>
@@ -15,8 +16,21 @@
 #include "../../include/raytracer_rs_amd.h"
 #include "rt_device.hpp"
 #include "rt_flatten.hpp"
+#include "rt_hostcopy.hpp"
 #include "rt_loader.hpp"
 #include "rt_math.hpp"
+
+// What rt_render keeps between calls on one handle: the frame in device memory, pinned staging memory of the same
+// size, two streams (kernels; device-to-host copies) and the events that order them.  Grown on demand, freed with the
+// handle.
+struct RenderPipe {
+    enum { MAX_GROUPS = 8 };
+    double *d_frame = nullptr, *h_stage = nullptr;
+    size_t d_cap = 0, h_cap = 0;  // bytes
+    hipStream_t s_render = nullptr, s_copy = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipEvent_t ev_rendered[MAX_GROUPS] = {}, ev_copied[MAX_GROUPS] = {};
+};
 
 struct rt_scene {
     int device = 0;
@@ -29,6 +43,7 @@ struct rt_scene {
     bool uneven = false;          // tiles differ in cost by more than a shadow ray: ordering them pays
     hipEvent_t marks[32][3] = {};  // event triples of the launches made with RT_RENDER_TIMED, used round-robin
     uint32_t timed_launches = 0;
+    RenderPipe pipe;
     rt::DeviceScene dev;
     std::vector<int32_t> object_to_leaf;
     uint64_t device_bytes = 0;
@@ -106,8 +121,8 @@ int render_rows(const rt_scene *scene, const rt_camera_desc *camera, const rt_re
     if (opts) {
         if (opts->max_depth < 0 || opts->max_depth > RT_MAX_DEPTH)
             return set_error(RT_ERR_INVALID_ARGUMENT, "max_depth must be within 0.." + std::to_string(RT_MAX_DEPTH));
-        depth = clamp_depth(opts->max_depth);
-        if (opts->flags & ~(RT_RENDER_TIMED | RT_RENDER_QUANTIZED)) return set_error(RT_ERR_INVALID_ARGUMENT, "unknown bits in flags");
+        depth = (opts->flags & RT_RENDER_EXACT_DEPTH) ? opts->max_depth : clamp_depth(opts->max_depth);
+        if (opts->flags & ~(RT_RENDER_TIMED | RT_RENDER_QUANTIZED | RT_RENDER_EXACT_DEPTH)) return set_error(RT_ERR_INVALID_ARGUMENT, "unknown bits in flags");
         if (opts->band_rows) {
             if (opts->band_step == 0) return set_error(RT_ERR_INVALID_ARGUMENT, "band_step must be positive");
             const uint32_t n_bands = (camera->vsize + opts->band_rows - 1) / opts->band_rows;
@@ -228,6 +243,17 @@ void rt_scene_destroy(rt_scene *scene) {
         if (scene->d_surfaces) (void)hipFree(scene->d_surfaces);
         if (scene->d_counters) (void)hipFree(scene->d_counters);
         if (scene->d_tiles) (void)hipFree(scene->d_tiles);
+        RenderPipe &p = scene->pipe;
+        if (p.d_frame) (void)hipFree(p.d_frame);
+        if (p.h_stage) (void)hipHostFree(p.h_stage);
+        if (p.s_render) (void)hipStreamDestroy(p.s_render);
+        if (p.s_copy) (void)hipStreamDestroy(p.s_copy);
+        if (p.ev_begin) (void)hipEventDestroy(p.ev_begin);
+        if (p.ev_end) (void)hipEventDestroy(p.ev_end);
+        for (int g = 0; g < RenderPipe::MAX_GROUPS; ++g) {
+            if (p.ev_rendered[g]) (void)hipEventDestroy(p.ev_rendered[g]);
+            if (p.ev_copied[g]) (void)hipEventDestroy(p.ev_copied[g]);
+        }
         for (auto &triple : scene->marks)
             for (hipEvent_t ev : triple)
                 if (ev) (void)hipEventDestroy(ev);
@@ -352,47 +378,115 @@ int rt_scene_render_times(const rt_scene *scene, uint32_t back, double *ordering
     return RT_OK;
 }
 
-int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts, double *rgb,
+// Makes sure the handle's pipeline can hold `bytes` of frame.
+static hipError_t pipe_prepare(RenderPipe &p, size_t bytes) {
+    hipError_t e = hipSuccess;
+    if (!p.s_render) e = hipStreamCreateWithFlags(&p.s_render, hipStreamNonBlocking);
+    if (e == hipSuccess && !p.s_copy) e = hipStreamCreateWithFlags(&p.s_copy, hipStreamNonBlocking);
+    if (e == hipSuccess && !p.ev_begin) e = hipEventCreate(&p.ev_begin);
+    if (e == hipSuccess && !p.ev_end) e = hipEventCreate(&p.ev_end);
+    for (int g = 0; e == hipSuccess && g < RenderPipe::MAX_GROUPS; ++g) {
+        if (!p.ev_rendered[g]) e = hipEventCreateWithFlags(&p.ev_rendered[g], hipEventDisableTiming);
+        if (e == hipSuccess && !p.ev_copied[g]) e = hipEventCreateWithFlags(&p.ev_copied[g], hipEventDisableTiming);
+    }
+    if (e == hipSuccess && bytes > p.d_cap) {
+        if (p.d_frame) (void)hipFree(p.d_frame);
+        p.d_frame = nullptr;
+        p.d_cap = 0;
+        e = hipMalloc((void **)&p.d_frame, bytes);
+        if (e == hipSuccess) p.d_cap = bytes;
+    }
+    if (e == hipSuccess && bytes > p.h_cap) {
+        if (p.h_stage) (void)hipHostFree(p.h_stage);
+        p.h_stage = nullptr;
+        p.h_cap = 0;
+        e = hipHostMalloc((void **)&p.h_stage, bytes, hipHostMallocDefault);
+        if (e == hipSuccess) p.h_cap = bytes;
+    }
+    return e;
+}
+
+// Camera::render into host memory.  The rows are rendered in a few groups; while the kernels of group k+1 run, group
+// k travels to pinned staging memory over PCIe and group k-1 is copied from there into the caller's frame by a few
+// host threads: the call costs about what the slowest of the three stages costs for the whole frame (for a
+// 3840x2160 f64 frame, 199 MB, that is the PCIe transfer), not their sum.
+int rt_render(const rt_scene *scene_c, const rt_camera_desc *camera, const rt_render_opts *opts, double *rgb,
               rt_stats *stats) {
     rt::RowMap rows;
     int depth;
     RtCameraDev cam;
-    int rc = render_rows(scene, camera, opts, rows, depth, cam);
+    int rc = render_rows(scene_c, camera, opts, rows, depth, cam);
     if (rc != RT_OK) return rc;
     if (!rgb) return set_error(RT_ERR_INVALID_ARGUMENT, "rgb must not be NULL");
-    if (opts && opts->flags) return set_error(RT_ERR_INVALID_ARGUMENT, "flags are for rt_render_device");
+    if (opts && (opts->flags & ~RT_RENDER_EXACT_DEPTH)) return set_error(RT_ERR_INVALID_ARGUMENT, "these flags are for rt_render_device");
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (rows.n_rows == 0) return RT_OK;
     const bool want_stats = opts && opts->collect_stats;
     if (want_stats && !stats) return set_error(RT_ERR_INVALID_ARGUMENT, "collect_stats needs a stats pointer");
+    rt_scene *scene = const_cast<rt_scene *>(scene_c);  // one call at a time per handle: the pipeline is the handle's
     DeviceGuard guard(scene->device);
     if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
     const size_t row_vals = (size_t)camera->hsize * 3;
-    const size_t count = (size_t)rows.n_rows * row_vals;
-    DeviceBuffer<double> buf;
-    HIP_TRY(buf.alloc(count));
+    const size_t row_bytes = row_vals * sizeof(double);
+    const size_t bytes = (size_t)rows.n_rows * row_bytes;
+    RenderPipe &p = scene->pipe;
+    HIP_TRY(pipe_prepare(p, bytes));
     uint32_t *tiles = nullptr;
     HIP_TRY(tile_scratch(scene, camera, rows, &tiles));
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    HIP_TRY(hipEventCreate(&ev0));
-    hipError_t e = hipEventCreate(&ev1);
-    if (e == hipSuccess && want_stats) e = hipMemsetAsync(scene->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), nullptr);
-    if (e == hipSuccess) e = hipEventRecord(ev0, nullptr);
-    if (e == hipSuccess) e = rt::launch_render(scene->dev, cam, rows, depth, buf.p, want_stats ? scene->d_counters : nullptr, tiles, nullptr);
-    if (e == hipSuccess) e = hipEventRecord(ev1, nullptr);
-    // packed rows -> their place in the caller's whole-frame buffer, one copy per band
-    for (uint32_t r = 0; e == hipSuccess && r < rows.n_rows; r += rows.band_rows) {
-        uint32_t y = rows.row_begin + (r / rows.band_rows) * rows.band_pitch;
-        uint32_t len = rows.n_rows - r < rows.band_rows ? rows.n_rows - r : rows.band_rows;
-        e = hipMemcpy(rgb + (size_t)y * row_vals, buf.p + (size_t)r * row_vals, (size_t)len * row_vals * sizeof(double),
-                      hipMemcpyDeviceToHost);
+
+    // Groups of packed rows [begin, end): whole bands (band mode) or multiples of the 8-row tile height, at least
+    // 8 MB each so that no stage is dominated by its fixed costs.
+    const bool banded = rows.band_pitch != 0;
+    const uint32_t unit = banded ? rows.band_rows : 8u;
+    uint32_t n_groups = (uint32_t)std::min<size_t>(RenderPipe::MAX_GROUPS, std::max<size_t>(1, bytes / (8u << 20)));
+    const uint32_t units = (rows.n_rows + unit - 1) / unit;
+    if (n_groups > units) n_groups = units;
+    uint32_t begin[RenderPipe::MAX_GROUPS + 1];
+    for (uint32_t g = 0; g <= n_groups; ++g) begin[g] = std::min<uint64_t>(rows.n_rows, (uint64_t)units * g / n_groups * unit);
+
+    hipError_t e = hipSuccess;
+    if (want_stats) e = hipMemsetAsync(scene->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), p.s_render);
+    if (e == hipSuccess) e = hipEventRecord(p.ev_begin, p.s_render);
+    for (uint32_t g = 0; e == hipSuccess && g < n_groups; ++g) {
+        rt::RowMap part = rows;
+        part.n_rows = begin[g + 1] - begin[g];
+        if (banded) {
+            part.row_begin = rows.row_begin + (begin[g] / rows.band_rows) * rows.band_pitch;
+        } else {
+            part.row_begin = rows.row_begin + begin[g];
+            part.row_end = rows.row_begin + begin[g + 1];
+            part.band_rows = part.n_rows;
+        }
+        const size_t at = (size_t)begin[g] * row_vals;
+        e = rt::launch_render(scene->dev, cam, part, depth, p.d_frame + at, want_stats ? scene->d_counters : nullptr, tiles, p.s_render);
+        if (e == hipSuccess && g + 1 == n_groups) e = hipEventRecord(p.ev_end, p.s_render);
+        if (e == hipSuccess) e = hipEventRecord(p.ev_rendered[g], p.s_render);
+        if (e == hipSuccess) e = hipStreamWaitEvent(p.s_copy, p.ev_rendered[g], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(p.h_stage + at, p.d_frame + at, (size_t)part.n_rows * row_bytes, hipMemcpyDeviceToHost, p.s_copy);
+        if (e == hipSuccess) e = hipEventRecord(p.ev_copied[g], p.s_copy);
+    }
+    // staged rows -> their place in the caller's whole-frame buffer
+    std::vector<rt::CopySegment> segments;
+    for (uint32_t g = 0; e == hipSuccess && g < n_groups; ++g) {
+        e = hipEventSynchronize(p.ev_copied[g]);
+        if (e != hipSuccess) break;
+        segments.clear();
+        for (uint32_t r = begin[g]; r < begin[g + 1]; r += rows.band_rows) {
+            const uint32_t y = rows.row_begin + (r / rows.band_rows) * rows.band_pitch + (banded ? 0 : r % rows.band_rows);
+            const uint32_t len = std::min(begin[g + 1] - r, rows.band_rows);
+            segments.push_back(rt::CopySegment{rgb + (size_t)y * row_vals, p.h_stage + (size_t)r * row_vals, (size_t)len * row_bytes});
+        }
+        rt::HostCopyPool::instance().run(segments);
+    }
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(p.s_render);  // nothing of this call may still be running when the caller's buffers go away
+        (void)hipStreamSynchronize(p.s_copy);
+        return hip_error(e, "rt_render");
     }
     float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+    e = hipEventElapsedTime(&ms, p.ev_begin, p.ev_end);
     unsigned long long c[RT_NUM_COUNTERS];
     if (e == hipSuccess && want_stats) e = hipMemcpy(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost);
-    (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
     if (e != hipSuccess) return hip_error(e, "rt_render");
     if (stats) {
         if (want_stats) stats_from_counters(c, stats);

@@ -672,6 +672,27 @@ def test_recursion_budget(gpu, rt, orc, depth):
     assert st.rays == oc.rays and st.reflect == oc.reflect and st.refract == oc.refract
 
 
+def test_render_with_zero_budget(gpu, rt, orc):
+    """Camera::render with `remaining` = 0 (world.rs:117): no reflection or refraction ray is spawned at all.  Through
+    rt_render and rt_render_device the budget 0 needs RT_RENDER_EXACT_DEPTH (zeroed options mean the default 5)."""
+    cam, world, ocam, oworld = load_both(rt, orc, "chapter_11", 120, 90)
+    scene = world.scene()
+    for depth in (0, 1, 5):
+        img, st = scene.render(cam, max_depth=depth, stats=True)
+        oc = orc.Counters()
+        px = [x for y in range(90) for x in range(120)]
+        py = [y for y in range(90) for x in range(120)]
+        rays = np.array([list(r.origin) + list(r.direction) for r in cam.rays_for_pixels(px, py)])
+        ref = np.array([oworld.color_at(orc.ray(r[:3], r[3:]), depth, oc) for r in rays]).reshape(90, 120, 3)
+        assert np.abs(img - ref).max() <= GUARD
+        assert (st.rays, st.reflect, st.refract) == (oc.rays, oc.reflect, oc.refract)
+        if depth == 0:
+            assert st.reflect == 0 and st.refract == 0
+    default, _ = scene.render(cam)
+    five, _ = scene.render(cam, max_depth=5)
+    assert np.array_equal(default, five)
+
+
 # --------------------------------------------------------------------------- full size
 def test_full_4k_frame(gpu, rt, orc):
     """The benchmark configuration itself: chapter_11 at 3840x2160, whole frame against the oracle, ray count exact,
