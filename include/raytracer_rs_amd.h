@@ -206,6 +206,28 @@ int rt_render_device_noalloc(const rt_scene *scene, const rt_camera_desc *camera
  * The caller must have synchronised the launch's stream first (RT_ERR_HIP otherwise). */
 int rt_scene_render_times(const rt_scene *scene, uint32_t back, double *ordering_ms, double *render_ms);
 
+/* Camera::render's row loop (rendering/camera.rs:58-64) over several GPUs of one node, driven from one process.  The
+ * reference renders its rows one after the other on one core; here the frame is cut into bands of rows and every GPU
+ * takes the next band from a shared cursor whenever it has fewer than two in flight, so that the GPUs finish together
+ * whatever the bands cost.  `devices` lists HIP device ordinals, one worker (host thread, stream, copy of the world)
+ * each; an ordinal may appear more than once (several workers on one GPU).  The frame is assembled on devices[0]. */
+typedef struct rt_multi rt_multi;
+int rt_multi_create(const rt_world_desc *world, const int *devices, uint32_t n_devices, rt_multi **out);
+void rt_multi_destroy(rt_multi *multi);
+/* The whole frame into device memory of devices[0] (vsize*hsize*3 doubles, or bytes with RT_RENDER_QUANTIZED), the
+ * call returning when it is complete.  Workers on devices[0] render into the frame directly; bands rendered on other
+ * GPUs are collected with RCCL (one group of ncclSend/ncclRecv pairs: each peer's bands over that peer's own xGMI link;
+ * librccl.so.1 is loaded when the first such handle is created).  Of opts: max_depth, collect_stats, flags
+ * (RT_RENDER_QUANTIZED, RT_RENDER_EXACT_DEPTH) and band_rows, the height of a band (0: about four bands per worker, at
+ * least 64 rows); everything else must be zero.  stats->kernel_ms is the wall-clock time of the rendering phase. */
+int rt_multi_render_device(rt_multi *multi, const rt_camera_desc *camera, const rt_render_opts *opts, void *frame_device,
+                           rt_stats *stats);
+/* The same into host memory (Canvas.pixels: vsize*hsize*3 doubles): every GPU sends its bands to the host itself, over
+ * its own PCIe link, and nothing travels between GPUs. */
+int rt_multi_render(rt_multi *multi, const rt_camera_desc *camera, const rt_render_opts *opts, double *rgb, rt_stats *stats);
+/* Measurement aid: how many bands each worker took in the last call (n = number of workers). */
+int rt_multi_bands_taken(const rt_multi *multi, uint32_t *per_worker, uint32_t n);
+
 /* World::color_at (rendering/world.rs:113-126) for n rays (6 doubles each: origin xyz, direction xyz) with the
  * given recursion budget (world.rs:117 `remaining`; pass RT_DEFAULT_DEPTH for color_at itself). */
 int rt_color_at(const rt_scene *scene, const double *rays, uint32_t n, int32_t remaining, double *colors,

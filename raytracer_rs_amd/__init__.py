@@ -3,7 +3,7 @@
 `SceneFile / Camera / World / Canvas` API."""
 from ._lib import (CONE, CUBE, CYLINDER, DEFAULT_DEPTH, GROUP, MAX_DEPTH, MAX_GROUP_NESTING, PATTERN_CHECKERS,
                    PATTERN_GRADIENT, PATTERN_NONE, PATTERN_RING, PATTERN_STRIPE, PLANE, SPHERE, RtError, Stats)
-from .api import (Camera, Canvas, Material, Matrix4, Object, Pattern, PointLight, Ray, Scene, SceneFile, World,
+from .api import (Camera, Canvas, Material, Matrix4, MultiScene, Object, Pattern, PointLight, Ray, Scene, SceneFile, World,
                   quantize_device, view_transform)
 
 __all__ = ["Camera", "Canvas", "Material", "Matrix4", "Object", "Pattern", "PointLight", "Ray", "Scene", "SceneFile",

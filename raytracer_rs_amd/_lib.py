@@ -111,6 +111,11 @@ SIGNATURES = {
     "rt_render_device": (C.c_int, [C.c_void_p, _P(CameraDesc), _P(RenderOpts), C.c_void_p, _P(Stats)]),
     "rt_render_device_noalloc": (C.c_int, [C.c_void_p, _P(CameraDesc), _P(RenderOpts), C.c_void_p]),
     "rt_scene_render_times": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_double), _P(C.c_double)]),
+    "rt_multi_create": (C.c_int, [_P(WorldDesc), _P(C.c_int), C.c_uint32, _P(C.c_void_p)]),
+    "rt_multi_destroy": (None, [C.c_void_p]),
+    "rt_multi_render_device": (C.c_int, [C.c_void_p, _P(CameraDesc), _P(RenderOpts), C.c_void_p, _P(Stats)]),
+    "rt_multi_render": (C.c_int, [C.c_void_p, _P(CameraDesc), _P(RenderOpts), _P(C.c_double), _P(Stats)]),
+    "rt_multi_bands_taken": (C.c_int, [C.c_void_p, _P(C.c_uint32), C.c_uint32]),
     "rt_color_at": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_int32, _P(C.c_double), _P(Stats)]),
     "rt_intersect": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, _P(C.c_double), _P(C.c_int32)]),
     "rt_intersect_all": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_uint32, _P(C.c_uint32), _P(C.c_double),

@@ -311,6 +311,7 @@ class Scene:
         cd = camera._desc()
         if out is None:
             out = np.zeros((camera.vsize, camera.hsize, 3), dtype=np.float64)
+        _check_frame(out, camera)
         opts = L.RenderOpts()
         if bands is not None:
             opts.band_rows, opts.band_first, opts.band_step = bands
@@ -468,6 +469,70 @@ class Scene:
         return out
 
 
+class MultiScene:
+    """A World resident on several GPUs of one node (`rt_multi`): bands of rows handed out dynamically, the frame
+    assembled on devices[0] (render_device) or in host memory (render)."""
+
+    def __init__(self, world_desc: L.WorldDesc, devices: Sequence[int], keepalive=None):
+        self._h = C.c_void_p()
+        self._keep = keepalive
+        self.devices = list(devices)
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        L.check(L.lib().rt_multi_create(C.byref(world_desc), arr, len(self.devices), C.byref(self._h)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            L.lib().rt_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _opts(self, band_rows: int, max_depth: Optional[int], stats: bool, quantized: bool) -> L.RenderOpts:
+        opts = L.RenderOpts()
+        opts.band_rows = band_rows
+        opts.collect_stats = int(stats)
+        opts.flags = L.RENDER_QUANTIZED if quantized else 0
+        _set_depth(opts, max_depth)
+        return opts
+
+    def render(self, camera: "Camera", band_rows: int = 0, max_depth: Optional[int] = None, stats: bool = False,
+               out: Optional[np.ndarray] = None):
+        """rt_multi_render into a host array [vsize, hsize, 3]; returns (array, Stats)."""
+        cd = camera._desc()
+        if out is None:
+            out = np.zeros((camera.vsize, camera.hsize, 3), dtype=np.float64)
+        _check_frame(out, camera)
+        opts = self._opts(band_rows, max_depth, stats, False)
+        st = L.Stats()
+        L.check(L.lib().rt_multi_render(self._h, C.byref(cd), C.byref(opts), out.ctypes.data_as(C.POINTER(C.c_double)),
+                                        C.byref(st)))
+        return out, st
+
+    def render_device(self, camera: "Camera", device_ptr: int, band_rows: int = 0, max_depth: Optional[int] = None,
+                      stats: bool = False, quantized: bool = False) -> L.Stats:
+        """rt_multi_render_device: the whole frame into memory of devices[0] at `device_ptr`; returns when complete."""
+        cd = camera._desc()
+        opts = self._opts(band_rows, max_depth, stats, quantized)
+        st = L.Stats()
+        L.check(L.lib().rt_multi_render_device(self._h, C.byref(cd), C.byref(opts), C.c_void_p(device_ptr), C.byref(st)))
+        return st
+
+    def bands_taken(self) -> List[int]:
+        arr = (C.c_uint32 * len(self.devices))()
+        L.check(L.lib().rt_multi_bands_taken(self._h, arr, len(self.devices)))
+        return list(arr)
+
+
+def _check_frame(out: np.ndarray, camera: "Camera") -> None:
+    """A caller-provided frame must be what the C side writes: float64, C-contiguous, [vsize, hsize, 3]."""
+    if out.dtype != np.float64 or not out.flags["C_CONTIGUOUS"] or out.shape != (camera.vsize, camera.hsize, 3):
+        raise ValueError(f"out must be a C-contiguous float64 array of shape ({camera.vsize}, {camera.hsize}, 3)")
+
+
 class World:
     """rendering/world.rs:14-17: `objects` + `light_source`.  Queries run on the GPU through a cached `Scene`;
     call `invalidate()` after mutating objects of a world that has already been used."""
@@ -518,6 +583,11 @@ class World:
         """Index of `obj` in the depth-first object list the device reports hits against."""
         self.scene()
         return self._index[id(obj)]
+
+    def multi_scene(self, devices: Sequence[int]) -> MultiScene:
+        """The world on several GPUs (a new rt_multi every call: the caller keeps it)."""
+        wd, keep = self.world_desc()
+        return MultiScene(wd, devices, keepalive=keep)
 
     def scene(self, device: int = -1) -> Scene:
         if self._scene is None:

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/raytracer_rs_amd.h"
+#include "rt_capi_internal.hpp"
 #include "rt_device.hpp"
 #include "rt_flatten.hpp"
 #include "rt_hostcopy.hpp"
@@ -158,6 +159,8 @@ int render_rows(const rt_scene *scene, const rt_camera_desc *camera, const rt_re
 }
 
 }  // namespace
+
+int rt::capi_set_error(int code, const std::string &msg) { return set_error(code, msg); }
 
 extern "C" {
 

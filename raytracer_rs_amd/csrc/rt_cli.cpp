@@ -1,9 +1,11 @@
 // rt_render: the command-line face of the library, standing in for the reference's `main` (main.rs:70-184), which
 // loads a scene file, renders it and writes a PPM per chapter.
 //
-//   rt_render <scene.toml> [-o out.ppm] [--width W --height H] [--device D] [--depth N] [--stats]
-//   rt_render --all-chapters <scenes_dir> <outputs_dir> [--device D]
+//   rt_render <scene.toml> [-o out.ppm] [--width W --height H] [--device D | --devices D0,D1,...] [--depth N] [--stats]
+//   rt_render --all-chapters <scenes_dir> <outputs_dir> [--device D | --devices D0,D1,...]
 //
+// --devices renders one frame on several GPUs (rt_multi_render: bands of rows taken from a shared cursor; an ordinal
+// may be listed more than once for several workers on one GPU).
 // The second form reproduces main()'s set of scene-file renders: chapter_5 .. chapter_14 into the reference's
 // output names.  (The chapter 2 and 4 plots of main() draw on a canvas directly and never touch the renderer;
 // JPEG output goes through a third-party encoder: neither is provided.)
@@ -24,7 +26,8 @@ int fail(const char *what) {
 
 struct Options {
     uint32_t width = 0, height = 0;
-    int device = 0, depth = 0;
+    int device = 0, depth = -1;  // depth < 0: the reference's default budget
+    std::vector<int> devices;    // non-empty: render on these GPUs together
     bool stats = false;
 };
 
@@ -34,6 +37,7 @@ int render_file(const std::string &scene_path, const std::string &out_path, cons
     rt_camera_desc cam;
     rt_world_desc world;
     rt_scene *scene = nullptr;
+    rt_multi *multi = nullptr;
     int rc = 1;
     std::vector<double> rgb;
     do {
@@ -45,14 +49,22 @@ int render_file(const std::string &scene_path, const std::string &out_path, cons
             cam = sized;
         }
         if (rt_scene_file_build_world(file, &world) != RT_OK) { fail("world"); break; }
-        if (rt_scene_create(&world, opt.device, &scene) != RT_OK) { fail("scene"); break; }
         rgb.resize((size_t)cam.hsize * cam.vsize * 3);
         rt_render_opts ro;
         std::memset(&ro, 0, sizeof ro);
-        ro.max_depth = opt.depth;
+        if (opt.depth >= 0) {
+            ro.max_depth = opt.depth;
+            ro.flags = RT_RENDER_EXACT_DEPTH;
+        }
         ro.collect_stats = opt.stats ? 1 : 0;
         rt_stats st;
-        if (rt_render(scene, &cam, &ro, rgb.data(), &st) != RT_OK) { fail("render"); break; }
+        if (!opt.devices.empty()) {
+            if (rt_multi_create(&world, opt.devices.data(), (uint32_t)opt.devices.size(), &multi) != RT_OK) { fail("scene"); break; }
+            if (rt_multi_render(multi, &cam, &ro, rgb.data(), &st) != RT_OK) { fail("render"); break; }
+        } else {
+            if (rt_scene_create(&world, opt.device, &scene) != RT_OK) { fail("scene"); break; }
+            if (rt_render(scene, &cam, &ro, rgb.data(), &st) != RT_OK) { fail("render"); break; }
+        }
         if (rt_canvas_write_ppm(rgb.data(), cam.hsize, cam.vsize, out_path.c_str()) != RT_OK) { fail(out_path.c_str()); break; }
         std::printf("%s -> %s  %ux%u  kernel %.3f ms", scene_path.c_str(), out_path.c_str(), cam.hsize, cam.vsize, st.kernel_ms);
         if (opt.stats)
@@ -63,6 +75,7 @@ int render_file(const std::string &scene_path, const std::string &out_path, cons
         rc = 0;
     } while (false);
     rt_scene_destroy(scene);
+    rt_multi_destroy(multi);
     rt_scene_file_free(file);
     return rc;
 }
@@ -87,6 +100,17 @@ int main(int argc, char **argv) {
         else if (a == "--width") opt.width = (uint32_t)std::strtoul(value("--width"), nullptr, 10);
         else if (a == "--height") opt.height = (uint32_t)std::strtoul(value("--height"), nullptr, 10);
         else if (a == "--device") opt.device = std::atoi(value("--device"));
+        else if (a == "--devices") {
+            for (const char *p = value("--devices"); *p;) {
+                char *end = nullptr;
+                opt.devices.push_back((int)std::strtol(p, &end, 10));
+                if (end == p) {
+                    std::fprintf(stderr, "rt_render: --devices wants a comma-separated list of ordinals\n");
+                    return 2;
+                }
+                p = *end == ',' ? end + 1 : end;
+            }
+        }
         else if (a == "--depth") opt.depth = std::atoi(value("--depth"));
         else if (a == "--stats") opt.stats = true;
         else if (a == "--all-chapters") all = true;
@@ -95,8 +119,8 @@ int main(int argc, char **argv) {
     }
     if ((all && pos.size() != 2) || (!all && pos.size() != 1) || (opt.width != 0) != (opt.height != 0)) {
         std::fprintf(stderr,
-                     "usage: rt_render <scene.toml> [-o out.ppm] [--width W --height H] [--device D] [--depth N] [--stats]\n"
-                     "       rt_render --all-chapters <scenes_dir> <outputs_dir> [--device D]\n");
+                     "usage: rt_render <scene.toml> [-o out.ppm] [--width W --height H] [--device D | --devices D0,D1,...] [--depth N] [--stats]\n"
+                     "       rt_render --all-chapters <scenes_dir> <outputs_dir> [--device D | --devices D0,D1,...]\n");
         return 2;
     }
     if (!all) {

@@ -672,6 +672,64 @@ def test_recursion_budget(gpu, rt, orc, depth):
     assert st.rays == oc.rays and st.reflect == oc.reflect and st.refract == oc.refract
 
 
+def test_several_workers_share_one_frame(gpu, rt, orc):
+    """rt_multi_*: the frame cut into bands that the workers take from a shared cursor.  Device 0 listed two and three
+    times gives several workers (host threads, streams, scene handles) on the one GPU a test box has; whatever the
+    interleaving, the frame must be the single-device frame bit for bit, in device memory (f64 and 8-bit) and in host
+    memory, and the counters must add up to the single-device counters."""
+    import ctypes
+    import subprocess
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    for name, (w, h) in (("chapter_11", (403, 301)), ("chapter_14", (320, 203))):
+        cam, world, _, _ = load_both(rt, orc, name, w, h)
+        full, st_full = world.scene().render(cam, stats=True)
+        buf = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(buf), full.nbytes + 64) == 0
+        try:
+            for devices, band_rows in (([0, 0], 0), ([0, 0, 0], 8), ([0], 24), ([0, 0], 1000)):
+                multi = world.multi_scene(devices)
+                n_bands = (h + (band_rows or 64) - 1) // (band_rows or 64)
+                # frame in device memory, f64
+                assert hip.hipMemset(buf, 0xA5, full.nbytes + 64) == 0
+                st = multi.render_device(cam, buf.value, band_rows=band_rows, stats=True)
+                got = np.zeros(full.nbytes + 64, dtype=np.uint8)
+                assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), buf, got.nbytes, 2) == 0
+                assert np.array_equal(got[:full.nbytes].view(np.float64).reshape(full.shape), full), (name, devices, band_rows)
+                assert (got[full.nbytes:] == 0xA5).all(), "wrote past the frame"
+                assert st.as_dict() == st_full.as_dict()
+                assert sum(multi.bands_taken()) == n_bands and len(multi.bands_taken()) == len(devices)
+                # 8-bit frame
+                st = multi.render_device(cam, buf.value, band_rows=band_rows, quantized=True)
+                q = np.zeros(w * h * 3, dtype=np.uint8)
+                assert hip.hipMemcpy(q.ctypes.data_as(ctypes.c_void_p), buf, q.nbytes, 2) == 0
+                assert np.array_equal(q.reshape(h, w, 3), orc.quantize(full))
+                # frame in host memory
+                host, st = multi.render(cam, band_rows=band_rows, stats=True)
+                assert np.array_equal(host, full) and st.rays == st_full.rays
+                multi.close()
+        finally:
+            hip.hipFree(buf)
+    # refused: row ranges, unknown devices
+    cam, world, _, _ = load_both(rt, orc, "chapter_6", 64, 64)
+    with pytest.raises(rt.RtError):
+        world.multi_scene([0, 99])
+    # the command-line renderer with --devices writes the reference's own file
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "raytracer_rs_amd", "rt_render")
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "rt_multi_chapter_6.ppm")
+    subprocess.run([exe, scene_path("chapter_6"), "-o", out, "--devices", "0,0"], check=True, capture_output=True)
+    import hashlib
+    import json
+    with open(os.path.join(GOLDEN, "MANIFEST.json")) as f:
+        manifest = json.load(f)
+    digest = hashlib.sha256(open(out, "rb").read()).hexdigest()
+    assert digest == manifest["ppm"]["chapter_6_sphere"]["sha256_p3_text"], "the PPM written through --devices is not the reference's file"
+
+
 def test_render_with_zero_budget(gpu, rt, orc):
     """Camera::render with `remaining` = 0 (world.rs:117): no reflection or refraction ray is spawned at all.  Through
     rt_render and rt_render_device the budget 0 needs RT_RENDER_EXACT_DEPTH (zeroed options mean the default 5)."""
