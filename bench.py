@@ -4,24 +4,31 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step is one whole frame.  With N ranks the frame's rows are cut into 16-row bands dealt round-robin to the ranks
-(band b -> rank b % N; band cost varies from ~1 ray/px in the sky to ~30 rays/px on the glass, and the fine interleave
-evens that out); every rank renders its bands with the HIP library into device memory (f64 colours), quantises them to the 8-bit
-frame a PPM is written from (canvas.rs:123-130, as a kernel; `--frame f64` keeps the f64 canvas instead), and the
-bands are gathered to rank 0 with one RCCL gather (grouped send/recv over xGMI) and copied into the frame.  The gather
-of frame k runs on its own stream and overlaps the rendering of frame k+1.  The scene is replicated, so the gather is
-the only collective.  The timed region starts with scene, camera and output buffers resident in HBM; it covers
-kernel + quantiser + gather + placement of the bands in the frame, K times, between barrier+synchronize pairs, and
-rank 0 reports the maximum over ranks.
+A step is one whole frame.  With N ranks (one process per GPU) the frame's rows are cut into 16-row bands dealt
+round-robin to the ranks (band b -> rank b % N; band cost varies from ~1 ray/px in the sky to ~30 rays/px on the glass,
+and the fine interleave evens that out); every rank renders its bands with the HIP library into device memory as the
+8-bit frame a PPM is written from (canvas.rs:123-130 applied by the render kernel; `--frame f64` keeps the f64 canvas
+instead), and the bands are gathered to rank 0 with one RCCL gather (grouped send/recv over xGMI) and copied into the
+frame.  The gather of frame k runs on its own stream and overlaps the rendering of frame k+1.  The scene is
+replicated, so the gather is the only collective.  The timed region starts with scene, camera and output buffers
+resident in HBM; it covers kernel + gather + placement of the bands in the frame, K times, between
+barrier+synchronize pairs, and rank 0 reports the maximum over ranks.
 
 Rank 0 prints ONE JSON line.  `value` = rays of the frame (a ray = one World::intersect call of the reference:
 camera, shadow, reflection and refraction rays; counted once by the library's counting kernel) x K / time.
 `roofline` prices the render kernel against the FP64 vector-ALU peak (nothing on this path is a dense contraction and
-the scene fits in cache, so neither "mfma" nor "hbm" is the bound that applies); `cpu_baseline` times the CPU oracle
-(the C restatement of the reference's algorithm, single-threaded like the reference and repeating its per-ray matrix
-inversions) on a bounded sample of rows of the same frame on this box's host cores.
+the scene fits in cache, so neither "mfma" nor "hbm" is the bound that applies), both the nominal figure and the
+rates a saturating v_fma_f64 / v_mul_f64+v_add_f64 stream reaches on this very GPU in this very run
+(tools/fp64_peak.hip).  On one GPU the line also carries: `f64_frame` (the same frame stored as the f64 canvas),
+`camera_render_ms` (the drop-in call itself, rt_render = Camera::render into HOST memory, PCIe included),
+`other_configs` (the other benchmark configurations of BASELINE.json, each with rays, kernel time and roofline
+fraction) and `cpu_baseline` (the CPU oracle -- the C restatement of the reference's algorithm, single-threaded like
+the reference and repeating its per-ray matrix inversions -- on a bounded sample of rows of the same frame on this
+box's host cores).
 """
 import argparse
+import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -40,12 +47,21 @@ from raytracer_rs_amd.dist import BandGather  # noqa: E402
 BAND_ROWS = 16
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 f64 lanes/clk x 2 (FMA) x 2.4 GHz = half the 157.3 TF f32 vector peak
 
-# Algorithmic flops per operation (add/sub/mul/div/sqrt/pow = 1 each; compares, abs, neg, min/max, floor free).
+# Algorithmic flops per operation of the reference (add/sub/mul/div/sqrt/pow = 1 each; compares, abs, neg, min/max,
+# floor free).  ray_transform is the reference's full 3x4 product (33); the kernel skips the products with the exact
+# zeros of a scale-and-translate inverse and executes 9 for those -- the algorithmic figure does not.
 FLOPS = {
     "ray_gen": 36, "ray_transform": 33, "aabb": 12,
     "prim_miss": (21, 0, 12, 44, 52), "prim_hit": (27, 1, 12, 44, 52),  # sphere, plane, cube, cylinder, cone
     "hit_record": 79, "shadow_setup": 18, "lighting_unlit": 29, "lighting_lit": 61, "pattern": 40,
     "reflect": 3, "refract_setup": 26, "schlick": 16, "combine": 6, "combine_schlick_extra": 7,
+}
+
+CONFIGS = {  # BASELINE.json configs[1..4]
+    "c2": ("chapter_7_and_8", 1920, 1080),
+    "c3": ("chapter_11", 3840, 2160),
+    "c4": ("chapter_14", 3840, 2160),
+    "c5": ("generated 10 001-leaf hierarchy (raytracer_rs_amd.synthetic.large_scene)", 7680, 4320),
 }
 
 
@@ -58,6 +74,81 @@ def algorithmic_flops(s: dict) -> float:
     f += FLOPS["pattern"] * s["patterns"] + FLOPS["reflect"] * s["reflect"] + FLOPS["refract_setup"] * s["refract_setups"]
     f += (FLOPS["schlick"] + FLOPS["combine_schlick_extra"]) * s["schlick"]
     return float(f)
+
+
+def scene_file_of(config: str):
+    """(SceneFile, path or None) of a benchmark configuration."""
+    if config == "c5":
+        from raytracer_rs_amd import synthetic
+
+        return rt.SceneFile.from_str(synthetic.large_scene()), None
+    path = os.path.join(ROOT, "tests", "golden", "scenes", CONFIGS[config][0] + ".toml")
+    return rt.SceneFile.from_file(path), path
+
+
+def measured_fp64_peak() -> dict:
+    """FP64 vector rates this GPU delivers right now: saturating v_fma_f64 stream, and v_mul_f64 / v_add_f64 stream."""
+    path = os.path.join(ROOT, "raytracer_rs_amd", "librt_peak.so")
+    if not os.path.exists(path):
+        return {}
+    lib = ctypes.CDLL(path)
+    f, u = ctypes.c_double(), ctypes.c_double()
+    if lib.rt_fp64_peak(ctypes.byref(f), ctypes.byref(u)) != 0:
+        return {}
+    return {"fma": f.value, "unfused": u.value}
+
+
+def device_source_hash() -> str:
+    h = hashlib.sha256()
+    for name in ("rt_device.hip", "rt_device_types.h", "rt_flatten.cpp"):
+        with open(os.path.join(ROOT, "raytracer_rs_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic() -> dict:
+    """HBM bytes per launch of the headline kernel from the committed PMC passes -- only while the kernel sources are
+    the ones that were profiled (their hash travels with the figure)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except Exception:
+        return {"traffic": None, "traffic_note": "no committed PMC summary"}
+    if t.get("source_sha256") != device_source_hash():
+        return {"traffic": None, "traffic_note": f"profiles/{t.get('profile', '?')} was taken on other kernel sources; not carried over"}
+    return {"traffic": t.get("hbm_bytes_per_launch"), "traffic_profile": t.get("profile"),
+            "executed_flops": t.get("executed_f64_flops_per_launch")}
+
+
+def kernel_name(scene) -> str:
+    info = scene.info()
+    return "render_kernel<false, 1, true>" if (info.n_groups > 0 or info.n_objects > 12) else "render_kernel<false, 0, false>"
+
+
+def time_config(scene, cam, stream, reps: int, quantized: bool) -> dict:
+    """Rays, algorithmic flops and GPU time of one configuration on one GPU (frame stays in HBM)."""
+    W, H = cam.hsize, cam.vsize
+    buf = torch.empty(W * H * 3, dtype=torch.uint8 if quantized else torch.float64, device="cuda")
+    st = scene.render_device(cam, buf.data_ptr(), None, None, stream, True, False, quantized)
+    counts = st.as_dict()
+    for _ in range(2):
+        scene.render_device(cam, buf.data_ptr(), None, None, stream, False, False, quantized)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        scene.render_device(cam, buf.data_ptr(), None, None, stream, False, True, quantized)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / reps * 1e3
+    times = [scene.render_times(back) for back in range(min(reps, 32))]
+    kernel_ms = sum(t[1] for t in times) / len(times)
+    ordering_ms = sum(t[0] for t in times) / len(times)
+    flops = algorithmic_flops(counts)
+    return {"rays": counts["rays"], "rays_per_pixel": round(counts["rays"] / (W * H), 3), "ms_per_frame": round(wall_ms, 4),
+            "kernel_ms": round(kernel_ms, 4), "tile_ordering_ms": round(ordering_ms, 4),
+            "mrays_per_s": round(counts["rays"] / wall_ms / 1e3, 1), "algorithmic_flops": flops,
+            "achieved_tflops": round(flops / (kernel_ms * 1e-3) / 1e12, 3),
+            "frac": round(flops / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 4), "kernel": kernel_name(scene)}
 
 
 def cpu_baseline(scene_path: str, width: int, height: int, seconds_target: float = 12.0) -> dict:
@@ -101,10 +192,13 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=25,
                     help="untimed frames first; the GPU takes about 20 frames of this size to reach its steady clocks")
-    ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "scenes", "chapter_11.toml"))
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3",
+                    help="benchmark configuration of BASELINE.json: c3 (default) is the headline, chapter_11 at 3840x2160")
+    ap.add_argument("--scene", default=None, help="a scene file instead of --config")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip other_configs, f64_frame and camera_render_ms")
     ap.add_argument("--check", action="store_true",
                     help="after the timed steps, rank 0 renders the whole frame by itself and compares the collected frame with it")
     ap.add_argument("--frame", choices=["f64", "u8"], default="u8",
@@ -124,11 +218,12 @@ def main() -> None:
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
     # Rehearsal on a box with fewer GPUs than ranks (RT_BENCH_BACKEND=gloo): ranks share devices and the gather goes
-    # through gloo; the real launch is one rank per GPU over nccl (= RCCL).
+    # through gloo (staged through host memory: gloo is a CPU backend); the real launch is one rank per GPU over nccl.
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
+    reduce_dev = dev if backend == "nccl" else torch.device("cpu")  # where tensors for all_reduce live
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -136,8 +231,14 @@ def main() -> None:
         else:
             dist.init_process_group(backend)
 
-    sf = rt.SceneFile.from_file(args.scene)
-    cam = sf.build_camera(args.width, args.height)
+    if args.scene:
+        sf, scene_path, name = rt.SceneFile.from_file(args.scene), args.scene, os.path.basename(args.scene)
+        width, height = args.width or 3840, args.height or 2160
+    else:
+        sf, scene_path = scene_file_of(args.config)
+        name, width, height = CONFIGS[args.config]
+        width, height = args.width or width, args.height or height
+    cam = sf.build_camera(width, height)
     world = sf.build_world()
     scene = world.scene(device_index)
     W, H = cam.hsize, cam.vsize
@@ -146,6 +247,7 @@ def main() -> None:
     bg = BandGather(W, H, rank, world_size, dev, BAND_ROWS, dtype=torch.uint8 if u8 else torch.float64,
                     collective_even_alone=multi)
     stream = torch.cuda.current_stream().cuda_stream
+
     def render_mine(k: int = 0, stats: bool = False, timed: bool = False):
         """Frame k: this rank's bands, rendered (and quantised) into the buffer the gather of frame k reads.
         `timed`: the library records HIP events on the launch's stream before the tile-ordering pass, between it and
@@ -172,7 +274,7 @@ def main() -> None:
     for k in rt.Stats.COUNT_FIELDS:
         v = counts[k]
         flat.extend(v if isinstance(v, list) else [v])
-    tot = torch.tensor(flat, dtype=torch.float64, device=dev)
+    tot = torch.tensor(flat, dtype=torch.float64, device=reduce_dev)
     if multi:
         dist.all_reduce(tot)
     tot = [int(v) for v in tot.tolist()]
@@ -201,11 +303,9 @@ def main() -> None:
         torch.cuda.synchronize()
     for k in range(args.warmup):
         step(k)
-    if multi and backend == "nccl":
+    if multi:
         # the same warm-up for several ranks, as whole steps (render and gather, exactly what the timed loop does);
-        # the ranks agree on when a tenth of a second has passed, so that all of them stop after the same step.
-        # (Not in the gloo rehearsal: there torch's gloo gather of device tensors stops returning after a handful
-        # of calls -- tools/gloo_gather_probe.py shows it without any of this code -- so a rehearsal is kept short.)
+        # the ranks agree on when a tenth of a second has passed, so that all of them stop after the same step
         t_pre = time.perf_counter()
         k = args.warmup
         while True:
@@ -214,7 +314,7 @@ def main() -> None:
                 k += 1
             bg.finish()
             torch.cuda.synchronize()
-            spent = torch.tensor([time.perf_counter() - t_pre], dtype=torch.float64, device=dev)
+            spent = torch.tensor([time.perf_counter() - t_pre], dtype=torch.float64, device=reduce_dev)
             dist.all_reduce(spent, op=dist.ReduceOp.MAX)
             if spent.item() >= 0.1:
                 break
@@ -237,7 +337,7 @@ def main() -> None:
     times = [scene.render_times(back) for back in range(min(args.steps, 32))]
     ordering_ms = sum(t[0] for t in times) / max(1, len(times))
     kernel_ms = sum(t[1] for t in times) / max(1, len(times))
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=reduce_dev)
     if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms_max = t.tolist()
@@ -258,16 +358,9 @@ def main() -> None:
     if rank == 0:
         ms_per_step = elapsed / max(1, args.steps) * 1e3
         achieved_tf = my_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                with open(pmc) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        headline = (args.config == "c3" and not args.scene and (W, H) == (3840, 2160))
         line = {
-            "metric": "Mrays/s, 3840x2160 chapter_11 scene" if (W, H) == (3840, 2160) else f"Mrays/s, {W}x{H} frame",
+            "metric": "Mrays/s, 3840x2160 chapter_11 scene" if headline else f"Mrays/s, {W}x{H} frame of {name}",
             "value": round(rays_frame * args.steps / elapsed / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -277,7 +370,7 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{os.path.basename(args.scene)} at {W}x{H}, depth 5, {BAND_ROWS}-row bands "
+            "config": {"workload": f"{name} at {W}x{H}, depth 5, {BAND_ROWS}-row bands "
                                    f"round-robin over {world_size} GPU(s), f64 colours -> "
                                    + ("8-bit frame (canvas.rs:123-130 applied by the render kernel) " if u8 else "f64 frame ")
                                    + "collected on rank 0",
@@ -285,17 +378,58 @@ def main() -> None:
                        "kernel_ms_max_over_ranks": round(kernel_ms_max, 4)},
             "roofline": {"bound": "valu_f64", "achieved": round(achieved_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved_tf / FP64_VECTOR_PEAK_TFLOPS, 4),
-                         "frac_of_unfused_ceiling": round(2.0 * achieved_tf / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "render_kernel<false, 0>", "kernel_ms": round(kernel_ms, 4),
+                         "frac_of_unfused_ceiling": round(2.0 * achieved_tf / FP64_VECTOR_PEAK_TFLOPS, 4),
+                         "kernel": kernel_name(scene), "kernel_ms": round(kernel_ms, 4),
                          "tile_ordering_ms": round(ordering_ms, 4),
                          "launches_averaged": len(times),
                          "algorithmic_flops_per_launch": my_flops,
                          "note": "FP64 vector ALU is the bounding unit (no dense contraction, scene cache-resident); "
                                  "peak counts an FMA as 2 flops, the kernel is built without FMA contraction to keep "
-                                 "the reference's rounding, so its own ceiling is half of peak"},
+                                 "the reference's rounding, so its own ceiling is half of peak; algorithmic flops count "
+                                 "the reference's 33-flop ray transform per object although the kernel executes 9 for "
+                                 "scale-and-translate inverses (every sphere of chapter_11)"},
         }
-        if not args.no_cpu_baseline and world_size == 1:
-            line["cpu_baseline"] = cpu_baseline(args.scene, W, H)
+        line["roofline"].update(committed_traffic() if headline and u8 else {"traffic": None})
+        if world_size == 1 and not multi:
+            peak = measured_fp64_peak()
+            if peak:
+                line["roofline"]["peak_measured_fma"] = round(peak["fma"], 2)
+                line["roofline"]["peak_measured_unfused"] = round(peak["unfused"], 2)
+                line["roofline"]["frac_of_measured_fma"] = round(achieved_tf / peak["fma"], 4)
+                line["roofline"]["frac_of_measured_unfused"] = round(achieved_tf / peak["unfused"], 4)
+            if not args.no_others:
+                f64 = time_config(scene, cam, stream, 20, False)
+                line["f64_frame"] = {"ms_per_step": f64["ms_per_frame"], "value": f64["mrays_per_s"], "kernel_ms": f64["kernel_ms"],
+                                     "note": "the same frame stored as the f64 canvas (Canvas.pixels, 24 B per pixel) in HBM"}
+                # the drop-in call: Camera::render into a host buffer, PCIe transfer and host copy included
+                host = np.zeros((H, W, 3))
+                for _ in range(3):
+                    scene.render(cam, out=host)
+                ts = []
+                for _ in range(10):
+                    t1 = time.perf_counter()
+                    scene.render(cam, out=host)
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                line["camera_render_ms"] = round(sorted(ts)[len(ts) // 2], 3)
+                line["camera_render_mrays_per_s"] = round(rays_frame / sorted(ts)[len(ts) // 2] / 1e3, 1)
+                del host
+                others = []
+                for cfg in ("c2", "c3", "c4", "c5"):
+                    if cfg == args.config and not args.scene and (W, H) == CONFIGS[cfg][1:]:
+                        continue
+                    osf, _ = scene_file_of(cfg)
+                    oscene = osf.build_world().scene(device_index)
+                    ocam = osf.build_camera(CONFIGS[cfg][1], CONFIGS[cfg][2])
+                    r = time_config(oscene, ocam, stream, 20 if cfg != "c5" else 5, True)
+                    r["config"] = cfg
+                    r["workload"] = f"{CONFIGS[cfg][0]} at {CONFIGS[cfg][1]}x{CONFIGS[cfg][2]}, depth 5, 8-bit frame in HBM"
+                    if peak:
+                        r["frac_of_measured_unfused"] = round(r["achieved_tflops"] / peak["unfused"], 4)
+                    others.append(r)
+                    oscene.close()
+                line["other_configs"] = others
+        if not args.no_cpu_baseline and world_size == 1 and scene_path:
+            line["cpu_baseline"] = cpu_baseline(scene_path, W, H)
         elif world_size == 1:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

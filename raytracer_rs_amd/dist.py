@@ -1,6 +1,7 @@
 """One frame over several GPUs of a node: row-band sharding and the gather of finished bands to rank 0.
 
-One process per GPU (`torch.distributed`, backend "nccl" = RCCL on ROCm; "gloo" for CPU rehearsal).  The scene is
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL on ROCm; "gloo" for rehearsal: bands then travel
+through pinned host memory, gloo being a CPU backend).  The scene is
 small and read-only, so every rank holds a copy; pixels are independent, so the only exchange is the gather of the
 rendered rows.  The frame is cut into bands of `band_rows` rows and band b belongs to rank b % world_size: band cost
 varies by an order of magnitude between sky and glass, and a fine round-robin interleave evens that out without any
@@ -71,6 +72,8 @@ class BandGather:
             self.frame = torch.zeros(self.n_bands, self.band_vals, dtype=dtype, device=device)
             if self.collective:
                 self._recv = [torch.empty_like(self.mine) for _ in range(world_size)]
+        self._host_send: Optional[torch.Tensor] = None  # pinned staging for a gloo gather of device bands
+        self._host_recv: Optional[List[torch.Tensor]] = None
         self._comm = None
         if device.type == "cuda" and self.collective:
             self._comm = torch.cuda.Stream(device=device)
@@ -106,6 +109,24 @@ class BandGather:
         return self.frame if self.rank == 0 else None
 
     def _gather_and_place(self, src: torch.Tensor) -> None:
+        if src.is_cuda and dist.get_backend() != "nccl":
+            # gloo is a CPU backend: handed device tensors it reads device memory from host threads, with no ordering
+            # against the stream that wrote it.  Bands therefore travel through pinned host memory: wait for the
+            # kernels queued so far, copy out, gather host tensors, copy the gathered bands back in.
+            if self._host_send is None:
+                self._host_send = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+                if self.rank == 0:
+                    self._host_recv = [torch.empty(src.shape, dtype=src.dtype, pin_memory=True) for _ in range(self.world_size)]
+            self._host_send.copy_(src, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            dist.gather(self._host_send, self._host_recv, dst=0)
+            if self.rank != 0:
+                return
+            for r in range(self.world_size):
+                k = len(range(r, self.n_bands, self.world_size))
+                self.frame[r::self.world_size] = self._host_recv[r][:k].to(self.frame.device, non_blocking=True)
+            torch.cuda.current_stream().synchronize()  # the pinned buffers are reused by the next call
+            return
         dist.gather(src, self._recv, dst=0)
         if self.rank != 0:
             return
