@@ -108,7 +108,10 @@ struct Reader {
         return true;
     }
 
-    bool object(const Value &tbl, const std::string &where, ObjectConfig &o) {
+    // `depth`: nesting level of the object (0 = the world's own list).  Deeper than the renderer walks is refused
+    // here: recursing through a file that nests `children` without end would overflow the stack.
+    bool object(const Value &tbl, const std::string &where, ObjectConfig &o, int depth = 0) {
+        if (depth > RT_MAX_GROUP_NESTING) return fail("groups are nested too deep (more than " + std::to_string(RT_MAX_GROUP_NESTING) + " levels) at " + where);
         if (tbl.type != Value::TABLE) return fail("invalid type: expected a table for " + where);
         const Value *ty = tbl.get("type");
         if (!ty) return fail("missing field `type` in " + where);
@@ -144,7 +147,7 @@ struct Reader {
                 if (ch->type != Value::ARRAY) return fail("invalid type: expected a sequence for `children` in " + where);
                 o.children.resize(ch->array.size());
                 for (size_t i = 0; i < ch->array.size(); ++i)
-                    if (!object(*ch->array[i], where + ".children[" + std::to_string(i) + "]", o.children[i])) return false;
+                    if (!object(*ch->array[i], where + ".children[" + std::to_string(i) + "]", o.children[i], depth + 1)) return false;
             }
         }
         return true;

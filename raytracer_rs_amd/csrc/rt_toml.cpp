@@ -299,7 +299,19 @@ struct Parser {
         return true;
     }
 
+    // Arrays and inline tables nest; a file that nests them thousands deep is broken or hostile, and recursing into
+    // it would overflow the stack instead of returning an error.
+    static constexpr int MAX_VALUE_DEPTH = 64;
+    int value_depth = 0;
+    struct DepthGuard {
+        int &d;
+        explicit DepthGuard(int &depth) : d(depth) { ++d; }
+        ~DepthGuard() { --d; }
+    };
+
     bool parse_value(Value &v) {
+        DepthGuard guard(value_depth);
+        if (value_depth > MAX_VALUE_DEPTH) return fail("values are nested too deep");
         skip_ws();
         char c = peek();
         if (c == '"' || c == '\'') {

@@ -30,6 +30,48 @@ def test_library_exports_every_declared_symbol(rt):
     assert lib.rt_abi_version() == 3
 
 
+def _c_declarations():
+    """(functions: name -> number of parameters, structs: name -> field names in order) of the C header."""
+    header = open(os.path.join(ROOT, "include", "raytracer_rs_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    funcs = {}
+    for m in re.finditer(r"\b(rt_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", header):
+        params = m.group(2).strip()
+        funcs[m.group(1)] = 0 if params in ("", "void") else len(params.split(","))
+    structs = {}
+    for m in re.finditer(r"typedef struct (rt_[a-z_]+)\s*\{(.*?)\}\s*\1\s*;", header, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.split(",")
+            names[0] = names[0].split()[-1]  # drop the type of the first declarator
+            fields += [re.sub(r"\[.*?\]", "", n).strip().lstrip("*") for n in names]
+        structs[m.group(1)] = fields
+    return funcs, structs
+
+
+def test_rust_sys_crate_declares_the_header(rt):
+    """bindings/rust/raytracer-rs-amd-sys/src/lib.rs cannot be compiled here (no Rust toolchain): check it textually
+    against the C header -- every rt_* function with the same number of parameters, every struct #[repr(C)] with the
+    same fields in the same order."""
+    funcs, structs = _c_declarations()
+    assert len(funcs) >= 30 and "rt_render_device_noalloc" in funcs and "rt_multi_render" in funcs
+    src = open(os.path.join(ROOT, "bindings", "rust", "raytracer-rs-amd-sys", "src", "lib.rs")).read()
+    rust_funcs = {}
+    for m in re.finditer(r"pub fn (rt_[a-z0-9_]+)\(([^)]*)\)", src):
+        params = m.group(2).strip()
+        rust_funcs[m.group(1)] = 0 if not params else len([p for p in params.split(",") if p.strip()])
+    assert rust_funcs == funcs, {k: (funcs.get(k), rust_funcs.get(k)) for k in set(funcs) | set(rust_funcs) if funcs.get(k) != rust_funcs.get(k)}
+    for name, fields in structs.items():
+        m = re.search(r"#\[repr\(C\)\]\s*(?:#\[derive\([^)]*\)\]\s*)?pub struct " + name + r"\s*\{(.*?)\}", src, flags=re.S)
+        assert m, f"{name} has no #[repr(C)] struct in lib.rs"
+        rust_fields = re.findall(r"pub (\w+)\s*:", m.group(1))
+        assert rust_fields == fields, (name, fields, rust_fields)
+    assert f"RT_ABI_VERSION: c_int = {rt._lib.lib().rt_abi_version()}" in src
+
+
 def test_struct_sizes_match_the_header(rt):
     """ctypes mirrors vs the C structs: compile a tiny C program against the header and compare sizeof."""
     import subprocess
@@ -159,12 +201,27 @@ unknown_key = "ignored"
     (MINIMAL + '[[objects]]\ntype = "sphere"\ntype = "plane"\n', -6, "duplicate key"),
     (MINIMAL + '[[objects]]\ntype = "sphere\n', -6, "line"),
     (MINIMAL + "[[objects]]\ntype = 1979-05-27\n", -6, "dates"),
+    # hostile nesting must come back as an error, not as a stack overflow
+    (MINIMAL + '[[objects]]\ntype = "sphere"\nx = ' + "[" * 100000 + "]" * 100000 + "\n", -6, "nested too deep"),
+    (MINIMAL + '[[objects]]\ntype = "group"\nchildren = [' + '{type = "group", children = [' * 40 + "]}" * 40 + "]\n", -6, "nested too deep"),
 ])
 def test_loader_errors_are_results_not_aborts(rt, text, code, needle):
     """SceneFile::from_file returns Err (loader.rs:190-194): here an RtError with RT_ERR_PARSE."""
     with pytest.raises(rt.RtError) as e:
         rt.SceneFile.from_str(text)
     assert e.value.code == code and needle in e.value.message, e.value.message
+
+
+def test_render_rejects_frames_that_are_not_the_canvas_layout(rt):
+    """Scene.render(out=...) hands the array's memory to C: anything but C-contiguous float64 [vsize, hsize, 3] is
+    refused before any call is made (no device needed to find that out)."""
+    from raytracer_rs_amd import api
+
+    cam = rt.Camera(8, 6, 1.0)
+    for bad in (np.zeros((6, 8, 3), dtype=np.float32), np.zeros((8, 6, 3)), np.zeros((6, 8, 4))[:, :, :3], np.zeros((6, 8))):
+        with pytest.raises(ValueError):
+            api._check_frame(bad, cam)
+    api._check_frame(np.zeros((6, 8, 3)), cam)
 
 
 def test_loader_io_error_and_negative_material(rt):
