@@ -1350,17 +1350,51 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void render_kernel(DeviceScene sce
     }
     V3 acc;
     radiance<NEST, STATS, TIES>(S, valid, ro, rd, max_depth, acc, ctr);
-    if (valid) {
-        size_t idx = ((size_t)r * cam.hsize + x) * 3;  // Canvas index (rendering/canvas.rs:40-42) within the rows rendered
-        if (rows.quantized) {
-            rows.quantized[idx] = quantize_value(acc.x);
-            rows.quantized[idx + 1] = quantize_value(acc.y);
-            rows.quantized[idx + 2] = quantize_value(acc.z);
-        } else {
-            rgb[idx] = acc.x;
-            rgb[idx + 1] = acc.y;
-            rgb[idx + 2] = acc.z;
+    // Canvas::write_pixel (rendering/canvas.rs:26-32) for the tile.  A lane's pixel is 3 values in the middle of a
+    // row, so lanes storing their own pixels write 24-byte (or 3-byte) pieces 24 (3) bytes apart.  A whole tile is
+    // instead laid out in LDS as its 8 rows of 24 values (the pending-ray stack is empty by now and lends the space)
+    // and stored row by row with consecutive lanes on consecutive words: 8-byte stores covering 192 contiguous bytes
+    // per tile row for the f64 canvas, one dword per lane for the 8-bit frame.
+    const size_t idx = ((size_t)r * cam.hsize + x) * 3;  // Canvas index (canvas.rs:40-42) within the rows rendered
+    const bool whole_tile = __ballot(valid) == ~0ull;
+    if (rows.quantized) {
+        const unsigned q0 = quantize_value(acc.x), q1 = quantize_value(acc.y), q2 = quantize_value(acc.z);
+        const size_t row_bytes = (size_t)cam.hsize * 3;
+        uint8_t *tile0 = rows.quantized + (size_t)((tile / tiles_x) * 8) * row_bytes + (size_t)((tile % tiles_x) * 8) * 3;
+        if (whole_tile && ((row_bytes | reinterpret_cast<size_t>(rows.quantized)) & 3) == 0) {
+            uint8_t *bytes = reinterpret_cast<uint8_t *>(ray_stack_lds + S.stack_base);  // 8 rows x 24 bytes
+            const unsigned at = (lane >> 3) * 24 + (lane & 7) * 3;
+            bytes[at] = (uint8_t)q0;
+            bytes[at + 1] = (uint8_t)q1;
+            bytes[at + 2] = (uint8_t)q2;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 48) {  // 6 dwords per tile row
+                const unsigned row = lane / 6, word = lane % 6;
+                const unsigned v = reinterpret_cast<const unsigned *>(bytes)[row * 6 + word];
+                *reinterpret_cast<unsigned *>(tile0 + row * row_bytes + word * 4) = v;
+            }
+        } else if (valid) {
+            rows.quantized[idx] = (uint8_t)q0;
+            rows.quantized[idx + 1] = (uint8_t)q1;
+            rows.quantized[idx + 2] = (uint8_t)q2;
         }
+    } else if (whole_tile) {
+        double *vals = ray_stack_lds + S.stack_base;  // 8 rows x 24 doubles
+        const unsigned at = (lane >> 3) * 24 + (lane & 7) * 3;
+        vals[at] = acc.x;
+        vals[at + 1] = acc.y;
+        vals[at + 2] = acc.z;
+        __builtin_amdgcn_wave_barrier();
+        double *tile0 = rgb + ((size_t)((tile / tiles_x) * 8) * cam.hsize + (size_t)((tile % tiles_x) * 8)) * 3;
+#pragma unroll
+        for (unsigned k = 0; k < 3; ++k) {
+            const unsigned j = lane + 64 * k;  // 192 values
+            tile0[(size_t)(j / 24) * cam.hsize * 3 + j % 24] = vals[j];
+        }
+    } else if (valid) {
+        rgb[idx] = acc.x;
+        rgb[idx + 1] = acc.y;
+        rgb[idx + 2] = acc.z;
     }
     flush_counters<STATS>(ctr, counters);
 }

@@ -403,6 +403,88 @@ def test_range_skipping_never_loses_a_hit(gpu, rt, orc):
     _lone_rays_agree(orc, world.scene(), oworld, rays)
 
 
+def test_range_skipping_on_rays_the_reference_treats_specially(gpu, rt, orc):
+    """Rays picked to sit on the thresholds a range-skip box has to be conservative about, inside a group with a
+    non-uniform scale and two rotations (so that box space, list space and world space all differ) and against a tiny
+    object far away (where an error of the reciprocal is multiplied by the distance):
+      * directions with |d_i| < EPSILON in a cube's space, which the reference calls parallel to the slab and then
+        accepts points up to EPSILON*t outside the cube (cubes.rs:47-53), from origins whose distance is just inside
+        and well outside the reach for which a box may still cull;
+      * directions with dx^2 + dz^2 below EPSILON in a cylinder's space (cylinders.rs:62-66: caps only);
+      * origins on or within 1e-7 of a surface, heading out: the hit at t = 0 counts, the one at t = -1e-7 does not;
+      * rays grazing the silhouette of a sphere of radius 0.022 (the smallest scale the reference can invert) from 4500
+        units away, with directions ten units long, so that the sphere is within the reach where boxes may cull.
+    Each ray alone in its wave, exact agreement with the oracle on object and distance."""
+    import tomli
+
+    head = ["[camera]", "width = 64", "height = 48", "fov = 60.0", "from = [0.0, 2.0, -30.0]", "to = [0.0, 0.0, 0.0]",
+            "up = [0.0, 1.0, 0.0]", "[light]", "position = [-10.0, 10.0, -10.0]", "intensity = [1.0, 1.0, 1.0]"]
+    lines = list(head)
+    lines += ["[[objects]]", 'type = "group"', "[objects.transform]", "translate = [1.0, -0.5, 2.0]", "scale = [3.0, 0.5, 1.5]",
+              "rotate_y = 30.0", "rotate_z = 20.0"]
+    kinds = []
+    for k in range(18):
+        kind = ("cube", "cylinder", "sphere")[k % 3]
+        kinds.append(kind)
+        lines += ["[[objects.children]]", f'type = "{kind}"']
+        if kind == "cylinder":
+            lines += ["minimum = -1.0", "maximum = 1.0", "closed = true"]
+        lines += ["[objects.children.transform]", f"translate = [{2.5 * k - 20.0}, {0.3 * (k % 4)}, {1.5 * (k % 5) - 3.0}]"]
+        if k % 2:
+            lines += [f"rotate_x = {15.0 * k}"]
+    # a dozen more top-level objects, so that the world's own list gets range-skip nodes too; the last one tiny and far
+    for k in range(12):
+        lines += ["[[objects]]", 'type = "cube"', "[objects.transform]", f"translate = [{-40.0 + 3.0 * k}, 8.0, 30.0]", "scale = [0.5, 0.5, 0.5]"]
+    lines += ["[[objects]]", 'type = "sphere"', "[objects.transform]", "translate = [4500.0, 0.0, 0.0]", "scale = [0.022, 0.022, 0.022]"]
+    text = "\n".join(lines) + "\n"
+    sf = rt.SceneFile.from_str(text)
+    _, oworld = orc.scene_from_dict(tomli.loads(text))
+    scene = sf.build_world().scene()
+    assert scene.info().n_groups == 1
+
+    G = orc.mul(orc.mul(orc.mul(orc.translate(1.0, -0.5, 2.0), orc.rotate_z(math.radians(20.0))), orc.rotate_y(math.radians(30.0))),
+                orc.scale(3.0, 0.5, 1.5)).numpy()
+
+    def to_world(o, d):  # a ray given in the group's space
+        o4, d4 = G @ np.array([*o, 1.0]), G @ np.array([*d, 0.0])
+        return [*o4[:3], *d4[:3]]
+
+    rays = []
+    eps_dirs = [(1.0, 9e-6, 0.0), (1.0, 0.0, 9e-6), (1.0, 1.1e-5, -9e-6), (-1.0, 9.9e-6, 9.9e-6), (1.0, -5e-6, 2e-5)]
+    for k in range(0, 18, 3):  # the cubes: child k sits at (2.5k - 20, 0.3(k%4), 1.5(k%5) - 3) in the group's space
+        cx, cy, cz = 2.5 * k - 20.0, 0.3 * (k % 4), 1.5 * (k % 5) - 3.0
+        for dist in (3.0, 120.0, 497.0, 503.0, 2500.0):
+            for d in eps_dirs:
+                for edge in (0.999995, 1.000004, -0.999995, 0.5):  # grazing a face just inside / just outside, and through the middle
+                    o = (cx - math.copysign(dist, d[0]), cy + edge, cz + 0.25 * edge)
+                    rays.append(to_world(o, d))
+    for k in range(1, 18, 3):  # the cylinders (odd k are rotated about x): rays almost along their axes, in their own space
+        cx, cy, cz = 2.5 * k - 20.0, 0.3 * (k % 4), 1.5 * (k % 5) - 3.0
+        R = orc.rotate_x(math.radians(15.0 * k)).numpy() if k % 2 else np.eye(4)
+        for tilt in (1e-3, 2e-3, 3.2e-3, 1e-4):
+            for off in (0.0, 0.5, 0.99, 1.01):
+                d = R @ np.array([tilt, 1.0, tilt, 0.0])
+                o = R @ np.array([off, -30.0, 0.1, 1.0])
+                rays.append(to_world((cx + o[0], cy + o[1], cz + o[2]), d[:3]))
+    for k in range(2, 18, 3):  # the spheres: origins on the surface and a hair inside / outside, heading out
+        cx, cy, cz = 2.5 * k - 20.0, 0.3 * (k % 4), 1.5 * (k % 5) - 3.0
+        for r in (1.0, 1.0 - 1e-7, 1.0 + 1e-7, 1.0 - 1e-9):
+            for n in ((1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.6, 0.0, 0.8)):
+                rays.append(to_world((cx + r * n[0], cy + r * n[1], cz + r * n[2]), n))
+    rng = np.random.default_rng(5)
+    for _ in range(200):  # the far, tiny sphere: aim at points on and around its silhouette as seen from near the origin
+        o = rng.uniform(-2.0, 2.0, size=3)
+        a = rng.uniform(0.0, 2.0 * math.pi)
+        r = 0.022 * (1.0 + rng.choice([-1e-3, -1e-5, 0.0, 1e-5, 1e-3, -0.5]))
+        target = np.array([4500.0, r * math.cos(a), r * math.sin(a)])
+        d = target - o
+        rays.append([*o, *(d / np.linalg.norm(d) * rng.choice([1.0, 10.0, 10.0]))])
+    rays = np.array(rays, dtype=np.float64)
+    hits = sum(oworld.hit(orc.ray(r[:3], r[3:])) is not None for r in rays)
+    assert hits >= len(rays) // 4, hits
+    _lone_rays_agree(orc, scene, oworld, rays)
+
+
 def test_cone_linear_shortcut_survives_range_skipping(gpu, rt, orc):
     """A ray with dx^2 - dy^2 + dz^2 below EPSILON in a cone's space: the reference takes t = -c / (2 b)
     (cones.rs:66-78), a point well off the cone and outside its bounding box, and accepts it because its y lies
