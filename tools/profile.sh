@@ -15,7 +15,7 @@ run() { # name, timeout, rocprof args...
     local name=$1 to=$2
     shift 2
     echo "== pass $name" >&2
-    timeout -s KILL "$to" rocprofv3 "$@" --output-format csv -d "$OUT" -o "$name" -- python3 bench.py --no-cpu-baseline \
+    timeout -s KILL "$to" rocprofv3 "$@" --output-format csv -d "$OUT" -o "$name" -- python3 bench.py --no-cpu-baseline --no-others \
         "${STEPS[@]}" "${EXTRA[@]}" > "$OUT/$name.bench.json" 2> "$OUT/$name.err"
     local rc=$?
     echo "   exit=$rc" >&2

@@ -27,7 +27,7 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
     ap.add_argument("needle", nargs="?", default="render_kernel<false")
-    ap.add_argument("--flops", type=float, default=0.0)
+    ap.add_argument("--flops", type=float, default=0.0, help="default: the figure perf.py printed in the kernel-trace run")
     ap.add_argument("--resource-usage", default=None)
     ap.add_argument("--note", default="")
     a = ap.parse_args()
@@ -42,6 +42,9 @@ def main() -> None:
              f"perf.py in the kernel-trace run: `{perf_line}`", ""]
     if a.note:
         lines += [a.note, ""]
+    m = re.search(r"flops ([0-9.e+]+)", perf_line)
+    if m and not a.flops:
+        a.flops = float(m.group(1))
 
     stats = os.path.join(src, "trace_kernel_stats.csv")
     shutil.copyfile(stats, os.path.join(dst, f"{a.tag}_kernel_stats.csv"))
