@@ -56,12 +56,19 @@ constexpr double EPS = 1e-5;          // core/floats.rs:2
 constexpr double AABB_EPS = 1e-10;    // geometry/bounds.rs:114
 constexpr double CHECKER_EPS = 1e-6;  // scene/patterns.rs:106
 constexpr int STACK_MAX = RT_MAX_DEPTH + 1;  // in memory: at most one parked ray per level, plus one while a hit pushes two
-constexpr int LDS_LEVELS = 2;                // of which the first ones are kept in LDS: 2 x 64 B per lane = 8 KB per wave
+// ... of which the first ones are kept in LDS, 64 B per lane and level = 4 KB per wave and level: two in the kernels
+// for flat scenes, one in those for scenes with groups, which also park a traversal ray in LDS (3 KB) and would
+// otherwise be limited to 14 waves per CU by their 11 KB (one level: chapter_14 -5 %, generated scene at 8K -6 %)
+#ifndef RT_NEST_LDS_LEVELS
+#define RT_NEST_LDS_LEVELS 1
+#endif
+template <int NEST>
+constexpr int LDS_LEVELS = NEST > 0 ? RT_NEST_LDS_LEVELS : 2;
 // Dynamic LDS of every kernel here, per wave of the workgroup: the LDS levels of the pending-ray stack (kernels that
 // run radiance()), then the slot in which a traversal parks the level-1 ray while it walks a nested group (kernels
 // built for scenes with groups: 6 x 64 doubles = 3 KB).  11 KB per wave for the render kernel of a scene with groups.
 template <int NEST, bool RADIANCE>
-constexpr unsigned LDS_WAVE_DOUBLES = ((RADIANCE ? LDS_LEVELS * 8 : 0) + (NEST > 0 ? 6 : 0)) * 64;
+constexpr unsigned LDS_WAVE_DOUBLES = ((RADIANCE ? LDS_LEVELS<NEST> * 8 : 0) + (NEST > 0 ? 6 : 0)) * 64;
 template <int NEST, bool RADIANCE>
 constexpr size_t lds_bytes(unsigned block) { return (size_t)(block / 64) * LDS_WAVE_DOUBLES<NEST, RADIANCE> * sizeof(double); }
 extern __shared__ double ray_stack_lds[];
@@ -927,6 +934,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
     double nx_w = 0.0;
     int nx_rem = -1;
     double *const lds = ray_stack_lds + S.stack_base + (threadIdx.x & 63u);
+    constexpr int LDS_LEVELS = rt::LDS_LEVELS<NEST>;
     double stk[STACK_MAX - LDS_LEVELS][7];
     int stk_rem[STACK_MAX - LDS_LEVELS];
     int sp = 0;
@@ -1153,7 +1161,7 @@ __device__ __forceinline__ SceneK scene_k(const DeviceScene &d, int max_depth) {
     S.n_nodes = d.n_nodes;
     S.max_depth = max_depth;
     S.stack_base = (unsigned)uniform((int)(threadIdx.x >> 6)) * LDS_WAVE_DOUBLES<NEST, RADIANCE>;
-    S.park_base = S.stack_base + (RADIANCE ? LDS_LEVELS * 8 * 64 : 0);
+    S.park_base = S.stack_base + (RADIANCE ? LDS_LEVELS<NEST> * 8 * 64 : 0);
     S.table_bytes = d.table_records * (unsigned)sizeof(RtNode);
     S.oct_tables = d.oct_tables;
     S.light = d.light;
@@ -1325,9 +1333,16 @@ __global__ __launch_bounds__(ORDER_BLOCK) void order_scatter_kernel(RowMap rows,
 }
 
 // Camera::render (rendering/camera.rs:56-67) for the rows of `rows`: one wave per 8x8 pixel tile.
-// Launched with one wave per workgroup (RENDER_BLOCK); four waves per SIMD: a budget of 128 VGPRs per lane.
+// Launched with one wave per workgroup (RENDER_BLOCK).  Flat scenes: four waves per SIMD, a budget of 128 VGPRs per
+// lane, which that kernel fits without spilling.  Scenes with groups: five waves per SIMD (96 VGPRs, some fifty of the
+// traversal's values spilled): their node tables do not fit the scalar cache, the record fetches miss, and a fifth
+// wave to switch to is worth more than the spills cost (chapter_14 at 4K -3 %, the generated scene at 8K -6 %; six
+// and eight waves gain nothing more).
 template <bool STATS, int NEST, bool TIES>
-__global__ __launch_bounds__(RENDER_BLOCK, 4) void render_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth,
+#ifndef RT_NEST_WAVES
+#define RT_NEST_WAVES 5
+#endif
+__global__ __launch_bounds__(RENDER_BLOCK, NEST > 0 ? RT_NEST_WAVES : 4) void render_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth,
                                                      double *__restrict__ rgb, unsigned long long *counters) {
     const unsigned lane = threadIdx.x & 63;
     unsigned tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
