@@ -483,18 +483,20 @@ int flatten_world(const rt_world_desc &world, FlatScene &out, std::string &err) 
     // whose tables come out identical (no split along some axis anywhere in the world) share one.
     std::vector<std::vector<RtNode>> tables;
     const unsigned n_oct = b.ordered ? 8u : 1u;
-    for (unsigned oct = 0; oct < n_oct; ++oct) {
+    static const unsigned oct_mask = (unsigned)env_size("RT_OCT_MASK", 7);  // (developer override: axes whose sign picks a table)
+    for (unsigned oct_index = 0; oct_index < n_oct; ++oct_index) {
+        const unsigned oct = oct_index & oct_mask;
         std::vector<RtNode> t;
         t.reserve(world.n_objects + world.n_objects / 2 + 1);
         b.nodes = &t;
-        b.counting = oct == 0;
+        b.counting = oct_index == 0;
         if (!b.emit_list(b.layouts[world.n_objects], 0, oct)) return b.code;
         t.emplace_back();  // one inert record past the end: the traversal fetches record i+1 while it works on record i
         std::memset(&t.back(), 0, sizeof(RtNode));
         size_t same = tables.size();
         for (size_t k = 0; k < tables.size(); ++k)
             if (tables[k].size() == t.size() && std::memcmp(tables[k].data(), t.data(), t.size() * sizeof(RtNode)) == 0) same = k;
-        out.oct_table[oct] = (uint8_t)same;
+        out.oct_table[oct_index] = (uint8_t)same;
         if (same == tables.size()) tables.push_back(std::move(t));
     }
     for (unsigned oct = n_oct; oct < 8; ++oct) out.oct_table[oct] = 0;

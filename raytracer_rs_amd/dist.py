@@ -69,11 +69,18 @@ class BandGather:
         self.frame: Optional[torch.Tensor] = None
         self._recv: Optional[List[torch.Tensor]] = None
         if rank == 0:
-            self.frame = torch.zeros(self.n_bands, self.band_vals, dtype=dtype, device=device)
+            # padded to slots * world_size bands, so that "band b belongs to rank b % world_size" is a plain reshape:
+            # frame_padded[slot, rank] is band slot * world_size + rank
+            self._frame_padded = torch.zeros(self.slots * world_size, self.band_vals, dtype=dtype, device=device)
+            self.frame = self._frame_padded[: self.n_bands]
             if self.collective:
-                self._recv = [torch.empty_like(self.mine) for _ in range(world_size)]
+                # one tensor [world_size, slots, band_vals]; the gather receives into its slices, and one strided
+                # copy puts every rank's bands in place (one kernel per frame, not one per rank)
+                self._recv_all = torch.empty(world_size, self.slots, self.band_vals, dtype=dtype, device=device)
+                self._recv = [self._recv_all[r] for r in range(world_size)]
         self._host_send: Optional[torch.Tensor] = None  # pinned staging for a gloo gather of device bands
         self._host_recv: Optional[List[torch.Tensor]] = None
+        self._host_recv_all: Optional[torch.Tensor] = None
         self._comm = None
         if device.type == "cuda" and self.collective:
             self._comm = torch.cuda.Stream(device=device)
@@ -116,23 +123,25 @@ class BandGather:
             if self._host_send is None:
                 self._host_send = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
                 if self.rank == 0:
-                    self._host_recv = [torch.empty(src.shape, dtype=src.dtype, pin_memory=True) for _ in range(self.world_size)]
+                    self._host_recv_all = torch.empty(self._recv_all.shape, dtype=src.dtype, pin_memory=True)
+                    self._host_recv = [self._host_recv_all[r] for r in range(self.world_size)]
             self._host_send.copy_(src, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             dist.gather(self._host_send, self._host_recv, dst=0)
             if self.rank != 0:
                 return
-            for r in range(self.world_size):
-                k = len(range(r, self.n_bands, self.world_size))
-                self.frame[r::self.world_size] = self._host_recv[r][:k].to(self.frame.device, non_blocking=True)
+            self._recv_all.copy_(self._host_recv_all, non_blocking=True)
+            self._place()
             torch.cuda.current_stream().synchronize()  # the pinned buffers are reused by the next call
             return
         dist.gather(src, self._recv, dst=0)
-        if self.rank != 0:
-            return
-        for r in range(self.world_size):
-            k = len(range(r, self.n_bands, self.world_size))
-            self.frame[r::self.world_size] = self._recv[r][:k]
+        if self.rank == 0:
+            self._place()
+
+    def _place(self) -> None:
+        """recv_all[rank, slot] -> frame band slot * world_size + rank, for every rank at once (bands past the end of
+        the frame land in its padding)."""
+        self._frame_padded.view(self.slots, self.world_size, self.band_vals).copy_(self._recv_all.permute(1, 0, 2))
 
     def finish(self) -> None:
         """Makes the current stream wait for every gather queued so far."""

@@ -97,6 +97,49 @@ def test_command_line_renderer_writes_the_reference_ppm(gpu, tmp_path):
     assert bad.returncode == 1 and "missing.toml" in bad.stderr
 
 
+def test_command_line_renderer_reproduces_mains_set_of_images(gpu, tmp_path):
+    """`rt_render --all-chapters` stands in for the reference's main() (main.rs:172-184): nine scene files in, nine PPMs
+    under the reference's output names out; the five whose PPM the reference ships are byte-identical to it."""
+    import hashlib
+    import json
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "raytracer_rs_amd", "rt_render")
+    done = subprocess.run([exe, "--all-chapters", os.path.join(GOLDEN, "scenes"), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0, done.stderr
+    with open(os.path.join(GOLDEN, "MANIFEST.json")) as f:
+        ppm = json.load(f)["ppm"]
+    names = ["chapter_5_circle", "chapter_6_sphere", "chapter_7_and_8_world", "chapter_9_plane_scene", "chapter_10_patterns",
+             "chapter_11_reflections", "chapter_12_cubes", "chapter_13_rocket", "chapter_14_groups"]
+    for name in names:
+        data = (tmp_path / (name + ".ppm")).read_bytes()
+        assert data.startswith(b"P3\n") and data.endswith(b"\n\n")
+        if name in ppm:
+            assert hashlib.sha256(data).hexdigest() == ppm[name]["sha256_p3_text"], name
+    assert sum(name in ppm for name in names) == 5
+
+
+def test_two_ranks_render_one_frame(gpu):
+    """The several-ranks path of bench.py with HIP kernels on every rank: two processes (sharing the one GPU of a test
+    box, process group on gloo, so the bands travel through pinned host memory) render their bands of the chapter_11
+    frame, rank 0 collects them and compares the frame with the one it renders alone (`--check`, exit status 3 on a
+    difference).  With RCCL the same code runs one rank per GPU."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(GOLDEN))
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo", RT_BENCH_WATCHDOG="100")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--check",
+           "--no-cpu-baseline", "--width", "960", "--height", "540"]
+    done = subprocess.run(cmd, capture_output=True, text=True, timeout=110, env=env, cwd=root)
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert "collected frame equals the single-GPU frame" in done.stderr
+    import json
+    line = json.loads(done.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["rays_per_frame"] > 960 * 540
+
+
 def test_device_quantiser_matches_host(gpu, rt):
     """canvas.rs:123-130 on a frame in device memory: ties away from zero, saturation, NaN -> 0."""
     import ctypes
