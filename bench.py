@@ -20,7 +20,7 @@ camera, shadow, reflection and refraction rays; counted once by the library's co
 the scene fits in cache, so neither "mfma" nor "hbm" is the bound that applies), both the nominal figure and the
 rates a saturating v_fma_f64 / v_mul_f64+v_add_f64 stream reaches on this very GPU in this very run
 (tools/fp64_peak.hip).  On one GPU the line also carries: `f64_frame` (the same frame stored as the f64 canvas),
-`camera_render_ms` (the drop-in call itself, rt_render = Camera::render into HOST memory, PCIe included),
+`two_frames_in_flight` (frames alternating between two handles on two streams), `camera_render_ms` (the drop-in call itself, rt_render = Camera::render into HOST memory, PCIe included),
 `other_configs` (the other benchmark configurations of BASELINE.json, each with rays, kernel time and roofline
 fraction) and `cpu_baseline` (the CPU oracle -- the C restatement of the reference's algorithm, single-threaded like
 the reference and repeating its per-ray matrix inversions -- on a bounded sample of rows of the same frame on this
@@ -401,6 +401,27 @@ def main() -> None:
                 f64 = time_config(scene, cam, stream, 20, False)
                 line["f64_frame"] = {"ms_per_step": f64["ms_per_frame"], "value": f64["mrays_per_s"], "kernel_ms": f64["kernel_ms"],
                                      "note": "the same frame stored as the f64 canvas (Canvas.pixels, 24 B per pixel) in HBM"}
+                # two frames in flight: a second handle of the same world on a second stream renders frame k+1 while
+                # frame k drains, so the under-occupied start and end of consecutive launches overlap (what a caller
+                # rendering a sequence of frames would do; the headline above is one frame at a time)
+                world2 = sf.build_world()
+                scene2 = world2.scene(device_index)
+                side = torch.cuda.Stream(device=dev)
+                frames = [torch.empty(W * H * 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+                handles, streams = [scene, scene2], [stream, side.cuda_stream]
+                for k in range(8):
+                    handles[k % 2].render_device(cam, frames[k % 2].data_ptr(), None, None, streams[k % 2], False, False, True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n_pipe = max(8, args.steps)
+                for k in range(n_pipe):
+                    handles[k % 2].render_device(cam, frames[k % 2].data_ptr(), None, None, streams[k % 2], False, False, True)
+                torch.cuda.synchronize()
+                pipe_ms = (time.perf_counter() - t1) / n_pipe * 1e3
+                line["two_frames_in_flight"] = {"ms_per_frame": round(pipe_ms, 4), "value": round(rays_frame / pipe_ms / 1e3, 1),
+                                                "note": "frames alternate between two handles of the world on two streams (8-bit frames in HBM)"}
+                scene2.close()
+                del frames
                 # the drop-in call: Camera::render into a host buffer, PCIe transfer and host copy included
                 host = np.zeros((H, W, 3))
                 for _ in range(3):
