@@ -292,7 +292,8 @@ struct Parser {
         if (clean.size() > 1 && clean[0] == '0') return fail("leading zero in integer '" + tok + "'");
         errno = 0;
         char *end = nullptr;
-        long long ll = std::strtoll((std::string(neg ? "-" : "") + clean).c_str(), &end, 10);
+        const std::string digits = std::string(neg ? "-" : "") + clean;  // must outlive `end`, which points into it
+        long long ll = std::strtoll(digits.c_str(), &end, 10);
         if (errno || *end) return fail("malformed number '" + tok + "'");
         v.type = Value::INTEGER;
         v.i = ll;

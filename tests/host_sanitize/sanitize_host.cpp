@@ -1,0 +1,144 @@
+// Host-side code of the library (scene-file reader, loader, world flattening, P3 writer) built with AddressSanitizer
+// and UndefinedBehaviorSanitizer and driven with the scene files given on the command line and with damaged copies
+// of them: truncations, byte flips, duplicated and deleted lines.  Every input must come back as a result (RT_OK or an
+// RT_ERR_* code with a message); a crash, an out-of-bounds access or undefined behaviour ends the program with a
+// sanitizer report and a non-zero status.  No GPU code is involved: nothing here includes the HIP runtime.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/raytracer_rs_amd.h"
+#include "../../raytracer_rs_amd/csrc/rt_flatten.hpp"
+#include "../../raytracer_rs_amd/csrc/rt_loader.hpp"
+
+namespace {
+
+uint64_t g_state = 0x5EED0001ull;
+uint64_t next() {  // SplitMix64
+    g_state += 0x9E3779B97F4A7C15ull;
+    uint64_t z = g_state;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct Tally {
+    unsigned parsed = 0, rejected = 0, flattened = 0, unflattenable = 0;
+};
+
+void feed(const std::string &text, Tally &tally) {
+    rt::SceneFile file;
+    std::string err;
+    if (rt::SceneFile::from_str(text, file, err) != RT_OK) {
+        if (err.empty()) {
+            std::fprintf(stderr, "a rejected scene came back without a message\n");
+            std::abort();
+        }
+        tally.rejected++;
+        return;
+    }
+    tally.parsed++;
+    rt_camera_desc cam;
+    file.build_camera(cam);
+    std::vector<rt_object_desc> objects;
+    rt_world_desc world;
+    if (file.build_world(objects, world, err) != RT_OK) {
+        tally.unflattenable++;
+        return;
+    }
+    rt::FlatScene flat;
+    if (rt::flatten_world(world, flat, err) != RT_OK) {
+        tally.unflattenable++;
+        return;
+    }
+    tally.flattened++;
+    // what the device would be handed: every link inside its table, every leaf index inside the surface table
+    const size_t per_table = flat.table_records;
+    for (size_t k = 0; k < flat.nodes.size(); ++k) {
+        const RtNode &n = flat.nodes[k];
+        const size_t local = k % per_table;
+        if (local + 1 == per_table) continue;  // the inert trailing record
+        if (n.skip < 0 || (size_t)n.skip >= per_table || (size_t)n.skip <= local || n.leaf >= (int32_t)flat.surfaces.size()) {
+            std::fprintf(stderr, "node %zu has skip %d / leaf %d outside its tables\n", k, n.skip, n.leaf);
+            std::abort();
+        }
+    }
+    RtCameraDev dev;
+    (void)rt::camera_to_device(cam, dev, err);
+}
+
+std::string damaged(const std::string &text) {
+    std::string t = text;
+    switch (next() % 6) {
+        case 0: t.resize(next() % (t.size() + 1)); break;                                  // truncate
+        case 1: for (int k = 0; k < 4 && !t.empty(); ++k) t[next() % t.size()] = (char)(next() & 0xff); break;  // flip bytes
+        case 2: {                                                                          // delete a line
+            const size_t a = t.find('\n', next() % (t.size() + 1));
+            const size_t b = a == std::string::npos ? a : t.find('\n', a + 1);
+            if (b != std::string::npos) t.erase(a, b - a);
+            break;
+        }
+        case 3: {                                                                          // duplicate a line
+            const size_t a = t.find('\n', next() % (t.size() + 1));
+            const size_t b = a == std::string::npos ? a : t.find('\n', a + 1);
+            if (b != std::string::npos) t.insert(b, t.substr(a, b - a));
+            break;
+        }
+        case 4: {                                                                          // a number becomes something else
+            static const char *const swaps[] = {"nan", "inf", "-inf", "1e400", "0", "-0.0", "\"x\"", "[1, 2]", "99999999999999999999", "{a = {b = {c = 1}}}"};
+            const size_t at = t.find_first_of("0123456789", next() % (t.size() + 1));
+            if (at != std::string::npos) {
+                const size_t end = t.find_first_not_of("0123456789.-+eE", at);
+                t.replace(at, (end == std::string::npos ? t.size() : end) - at, swaps[next() % 10]);
+            }
+            break;
+        }
+        default: t.insert(next() % (t.size() + 1), "\n[[objects.children]]\ntype = \"group\"\n"); break;  // nest deeper
+    }
+    return t;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    Tally tally;
+    for (int i = 1; i < argc; ++i) {
+        std::ifstream in(argv[i], std::ios::binary);
+        std::stringstream ss;
+        ss << in.rdbuf();
+        const std::string text = ss.str();
+        const unsigned before = tally.flattened;
+        feed(text, tally);
+        if (tally.flattened != before + 1) {
+            std::fprintf(stderr, "%s did not load\n", argv[i]);
+            return 1;
+        }
+        for (int k = 0; k < 300; ++k) {
+            std::string t = damaged(text);
+            if (next() % 3 == 0) t = damaged(t);
+            feed(t, tally);
+        }
+    }
+    // the P3 writer on awkward values (NaN, infinities, negative zero, exactly .5 after scaling) and awkward sizes
+    const double odd[] = {0.0, -0.0, 1.0, 0.5 / 255.0, 1.5 / 255.0, 254.5 / 255.0, 2.0, -3.0, 1e308, -1e308,
+                          std::numeric_limits<double>::quiet_NaN(), std::numeric_limits<double>::infinity(),
+                          -std::numeric_limits<double>::infinity(), 0.999999999, 1e-320};
+    for (uint32_t w : {1u, 2u, 5u, 6u, 17u, 23u, 24u, 70u})
+        for (uint32_t h : {1u, 3u}) {
+            std::vector<double> rgb((size_t)w * h * 3);
+            for (double &v : rgb) v = odd[next() % (sizeof odd / sizeof odd[0])];
+            const size_t need = rt_canvas_to_ppm(rgb.data(), w, h, nullptr, 0);
+            std::vector<char> out(need);
+            if (rt_canvas_to_ppm(rgb.data(), w, h, out.data(), need) != need) return 1;
+            std::vector<uint8_t> q(rgb.size());
+            if (rt_canvas_quantize(rgb.data(), rgb.size(), q.data()) != RT_OK) return 1;
+        }
+    std::printf("sanitized host run: %u inputs parsed (%u flattened, %u refused by the loader or the flattener), %u rejected by the reader\n",
+                tally.parsed, tally.flattened, tally.unflattenable, tally.rejected);
+    return 0;
+}
