@@ -689,13 +689,12 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
         bb[1] = w.a1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) bb[2 + k] = dwords_to_double(raw.c[2 * k], raw.c[2 * k + 1]);
-        // The record to have ready next: the following one -- except after a range-skip node, which more often
-        // than not sends the traversal to `skip` (the table has one spare record at its end).
-        const int guess = (kind == RT_SKIPBOX && !STATS && !B::every) ? w.skip : i + 1;
-        asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(ld.x), "+v"(ld.y), "+v"(ld.z));  // the transform is complete
-        NodeRaw nraw = node_fetch<true>(nodes, guess);
-        int ni = i + 1;
-        RT_NODE_VISIT(kind == RT_SKIPBOX ? 0 : kind == RT_GROUP ? 1 : 2);
+        // The record to have ready next.  A range-skip node sends the traversal on to `skip` about every other time,
+        // so there is nothing to guess from: its test (which needs nothing but the record and the ray) runs first and
+        // the request goes out for the record that is certain to be next.  After every other kind of node the
+        // following record is asked for before the test (the table has one spare record at its end); only a group
+        // that no ray enters, one in twenty, makes that the wrong one.
+        int guess = i + 1;
         if (kind == RT_SKIPBOX) {
             if constexpr (!STATS && !B::every) {  // the counting kernel visits everything the reference visits
                 if (!have_inv) {
@@ -705,9 +704,14 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
                 }
                 const bool may = active && !settled(best) && (shortcut || box_may_hit(bb, co, inv_d, dmax, hit_limit(best, far)));
                 ctr.visits += may ? 1u : 0u;
-                if (__ballot(may) == 0ull) ni = w.skip;
+                if (__ballot(may) == 0ull) guess = w.skip;
             }
-        } else if (kind == RT_GROUP) {
+        }
+        asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(ld.x), "+v"(ld.y), "+v"(ld.z));  // the transform is complete
+        NodeRaw nraw = node_fetch<true>(nodes, guess);
+        int ni = guess;
+        RT_NODE_VISIT(kind == RT_SKIPBOX ? 0 : kind == RT_GROUP ? 1 : 2);
+        if (kind == RT_GROUP) {
             // Group: bounds in the group's own space against the ray in that space (world.rs:44-63)
             bool inside = false;
             if (active) {
@@ -726,7 +730,7 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
                 have_inv = false;
                 ni = i + 1;
             }
-        } else {
+        } else if (kind != RT_SKIPBOX) {
             const bool any = hit_leaf<false, STATS, B>(kind, w.tag, lo, ld, w.a0, w.a1, active, w.leaf, best);
             if (STATS && active) {
                 ctr.add(C_XFORM);

@@ -66,6 +66,11 @@ static size_t env_size(const char *name, size_t fallback) {
 static const size_t SKIP_MIN_LIST = env_size("RT_SKIP_MIN_LIST", 12);
 static const size_t SKIP_RUN = env_size("RT_SKIP_RUN", 6);
 static const size_t SKIP_WIDE = env_size("RT_SKIP_WIDE", 24);  // lists longer than this are cut in four parts at a time, not two
+// A cube, cylinder or cone gets a range-skip node of its own when its box is small inside the box that was tested
+// just before it (surface areas: the share of the rays through the outer box that also pass through the inner one);
+// a box that most of those rays pass anyway costs a test and a record and saves nothing.  In percent.
+static const size_t SKIP_WRAP_PERCENT = env_size("RT_SKIP_WRAP_PERCENT", 50);
+static const size_t SKIP_PART_PERCENT = env_size("RT_SKIP_PART_PERCENT", 75);
 
 // The directions for which some cone below a node takes the shortcut of cones.rs:66-78: with a = dx^2 - dy^2 + dz^2
 // of the ray in the cone's space below EPSILON, the reference accepts t = -c / (2 b) -- a point that need not lie on
@@ -275,20 +280,64 @@ struct Builder {
             L.tree[(size_t)at].member = *lo;
             return at;
         }
-        double cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (auto it = lo; it != hi; ++it)
-            for (int a = 0; a < 3; ++a) {
-                cmin[a] = std::fmin(cmin[a], centre(*it, a));
-                cmax[a] = std::fmax(cmax[a], centre(*it, a));
-            }
+        static const size_t use_sah = env_size("RT_SAH", 1);
         int axis = 0;
-        for (int a = 1; a < 3; ++a)
-            if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
-        const auto mid = lo + (std::ptrdiff_t)(n / 2);
-        std::nth_element(lo, mid, hi, [&](uint32_t x, uint32_t y) {
-            const double cx = centre(x, axis), cy = centre(y, axis);
-            return cx < cy || (cx == cy && x < y);
-        });
+        auto mid = lo + (std::ptrdiff_t)(n / 2);
+        if (use_sah && n >= 3) {
+            // The cut, along any of the three axes (members sorted by their centres), for which the two sides' boxes
+            // are smallest for what they hold: surface of the side's box times its member count, summed over both.
+            double best = INFINITY;
+            size_t best_at = n / 2;
+            std::vector<uint32_t> sorted(lo, hi), best_order;
+            std::vector<double> right_area(n);
+            for (int a = 0; a < 3; ++a) {
+                std::sort(sorted.begin(), sorted.end(), [&](uint32_t x, uint32_t y) {
+                    const double cx = centre(x, a), cy = centre(y, a);
+                    return cx < cy || (cx == cy && x < y);
+                });
+                Bounds acc = Bounds::empty();
+                for (size_t k = n; k-- > 1;) {
+                    acc = acc.merge(in_parent[sorted[k]]);
+                    right_area[k] = surface(acc);
+                }
+                acc = Bounds::empty();
+                for (size_t k = 1; k < n; ++k) {
+                    acc = acc.merge(in_parent[sorted[k - 1]]);
+                    const double cost = surface(acc) * (double)k + right_area[k] * (double)(n - k);
+                    if (cost < best) {
+                        best = cost;
+                        best_at = k;
+                        axis = a;
+                        best_order.clear();
+                    }
+                }
+                if (best_order.empty() && axis == a) best_order = sorted;
+            }
+            if (!best_order.empty() && std::isfinite(best)) {
+                std::copy(best_order.begin(), best_order.end(), lo);
+                mid = lo + (std::ptrdiff_t)best_at;
+            } else {
+                axis = -1;
+            }
+        } else {
+            axis = -1;
+        }
+        if (axis < 0) {
+            double cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (auto it = lo; it != hi; ++it)
+                for (int a = 0; a < 3; ++a) {
+                    cmin[a] = std::fmin(cmin[a], centre(*it, a));
+                    cmax[a] = std::fmax(cmax[a], centre(*it, a));
+                }
+            axis = 0;
+            for (int a = 1; a < 3; ++a)
+                if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+            mid = lo + (std::ptrdiff_t)(n / 2);
+            std::nth_element(lo, mid, hi, [&](uint32_t x, uint32_t y) {
+                const double cx = centre(x, axis), cy = centre(y, axis);
+                return cx < cy || (cx == cy && x < y);
+            });
+        }
         const int32_t l = build_tree(L, lo, mid), r = build_tree(L, mid, hi);
         OrderNode &t = L.tree[(size_t)at];
         t.axis = axis;
@@ -323,19 +372,31 @@ struct Builder {
     // Emits the members below `node` of a list's order tree, wrapping sub-ranges of long lists in range-skip nodes:
     // lists longer than SKIP_MIN_LIST are cut in two or (above 4 runs) four parts, recursively, until a part has at
     // most SKIP_RUN members; every part of two or more members gets a node.
-    bool emit_tree(const ListLayout &L, int32_t node, uint32_t depth, unsigned oct, bool whole_list) {
+    static double surface(const Bounds &b) {
+        const double x = b.max.x - b.min.x, y = b.max.y - b.min.y, z = b.max.z - b.min.z;
+        return x * y + y * z + z * x;
+    }
+    Bounds around(const std::vector<uint32_t> &members) const {
+        Bounds u = Bounds::empty();
+        for (uint32_t k : members) u = u.merge(in_parent[k]);
+        return u;
+    }
+    // `outer`: surface of the box (range-skip node or the list's own bounds) tested last before these members.
+    bool emit_tree(const ListLayout &L, int32_t node, uint32_t depth, unsigned oct, bool whole_list, double outer) {
         const OrderNode &t = L.tree[(size_t)node];
         const size_t n = t.count;
         if (n <= (whole_list ? SKIP_MIN_LIST : SKIP_RUN)) {
             std::vector<uint32_t> members;
             collect(L, node, oct, members);
             for (uint32_t m : members) {
-                // A member whose own test is expensive next to a box test (a group: ray transform + six divisions;
-                // cube, cylinder, cone: ray transform + a long intersection routine) gets a node of its own in front.
+                // A member whose own test is expensive next to a box test gets a node of its own in front: a group
+                // (ray transform + six divisions) always, a cube, cylinder or cone (ray transform + a long
+                // intersection routine) when the box test is likely to fail.
                 const int kind = world.objects[m].kind;
                 double box[6];
                 ConeDirs dirs;
-                const bool wrap = ordered && kind != RT_SPHERE && kind != RT_PLANE && skip_box({m}, box, dirs);
+                const bool worth = kind == RT_GROUP || surface(in_parent[m]) * 100.0 < outer * (double)SKIP_WRAP_PERCENT;
+                const bool wrap = ordered && kind != RT_SPHERE && kind != RT_PLANE && worth && skip_box({m}, box, dirs);
                 const size_t ni = nodes->size();
                 if (wrap) push_skip(box, dirs, depth);
                 if (!emit(m, depth, oct)) return false;
@@ -362,12 +423,12 @@ struct Builder {
             collect(L, part, oct, members);
             double box[6];
             ConeDirs dirs;
-            if (members.size() >= 2 && skip_box(members, box, dirs)) {
+            if (members.size() >= 2 && surface(around(members)) * 100.0 < outer * (double)SKIP_PART_PERCENT && skip_box(members, box, dirs)) {
                 const size_t ni = nodes->size();
                 push_skip(box, dirs, depth);
-                if (!emit_tree(L, part, depth, oct, false)) return false;
+                if (!emit_tree(L, part, depth, oct, false, surface(around(members)))) return false;
                 (*nodes)[ni].skip = (int32_t)nodes->size();
-            } else if (!emit_tree(L, part, depth, oct, false)) {
+            } else if (!emit_tree(L, part, depth, oct, false, outer)) {
                 return false;
             }
         }
@@ -377,7 +438,10 @@ struct Builder {
     bool emit_list(const ListLayout &L, uint32_t depth, unsigned oct) {
         for (uint32_t m : L.unbounded)
             if (!emit(m, depth, oct)) return false;
-        return L.root < 0 || emit_tree(L, L.root, depth, oct, true);
+        if (L.root < 0) return true;
+        std::vector<uint32_t> members;
+        collect(L, L.root, oct, members);
+        return emit_tree(L, L.root, depth, oct, true, surface(around(members)));
     }
 
     // Appends object `idx` and its subtree.
