@@ -55,22 +55,22 @@ Bounds leaf_bounds(const rt_object_desc &o) {
     }
 }
 
-// Range-skip nodes (see RT_SKIPBOX in rt_device_types.h): sibling lists longer than SKIP_MIN_LIST are cut into
-// runs, recursively, until a run has at most SKIP_RUN members; every run of two or more bounded siblings gets a node.
-// Short lists are left alone: a test per node is cheaper than the wider record fetch and the extra branches.
+// Range-skip nodes (see RT_SKIPBOX in rt_device_types.h).  A world without groups whose list has at most
+// SKIP_MIN_LIST members is left as the reference has it: a test per member is cheaper there than wider records and
+// extra branches.  Everywhere else every sibling list gets an order tree, and the tree nodes that become range-skip
+// nodes are chosen by expected cost (Builder::plan).
 static size_t env_size(const char *name, size_t fallback) {
     const char *e = std::getenv(name);
     return e && *e ? (size_t)std::strtoul(e, nullptr, 10) : fallback;
 }
-// (developer overrides for tuning runs: RT_SKIP_MIN_LIST, RT_SKIP_RUN, RT_SKIP_WIDE)
-static const size_t SKIP_MIN_LIST = env_size("RT_SKIP_MIN_LIST", 12);
-static const size_t SKIP_RUN = env_size("RT_SKIP_RUN", 6);
-static const size_t SKIP_WIDE = env_size("RT_SKIP_WIDE", 24);  // lists longer than this are cut in four parts at a time, not two
-// A cube, cylinder or cone gets a range-skip node of its own when its box is small inside the box that was tested
-// just before it (surface areas: the share of the rays through the outer box that also pass through the inner one);
-// a box that most of those rays pass anyway costs a test and a record and saves nothing.  In percent.
-static const size_t SKIP_WRAP_PERCENT = env_size("RT_SKIP_WRAP_PERCENT", 50);
-static const size_t SKIP_PART_PERCENT = env_size("RT_SKIP_PART_PERCENT", 75);
+static const size_t SKIP_MIN_LIST = env_size("RT_SKIP_MIN_LIST", 12);  // (developer override for tuning runs)
+// What a wave spends on one record, in vector instructions, the traversal loop's own share included: the figures
+// the choice of range-skip nodes is made with.  (Developer override: RT_COST_BOX.)
+static const double COST_BOX = (double)env_size("RT_COST_BOX", 80);  // a range-skip node: slab test, reach guard, its record
+static const double COST_RECORD = 20.0;                              // the loop's own work per record
+static const double COST_RAY_GENERAL = 33.0, COST_RAY_DIAGONAL = 9.0;  // the ray into a node's space
+static const double COST_BOUNDS = 75.0;                              // a group's bounds test with its six divisions
+static const double COST_LEAF[5] = {25.0, 8.0, 60.0, 70.0, 80.0};    // intersection routine: sphere, plane, cube, cylinder, cone
 
 // The directions for which some cone below a node takes the shortcut of cones.rs:66-78: with a = dx^2 - dy^2 + dz^2
 // of the ray in the cone's space below EPSILON, the reference accepts t = -c / (2 b) -- a point that need not lie on
@@ -152,6 +152,7 @@ struct Builder {
     // per object, from measure(): Shape::bounds() in its own space, the same in its parent's space, its children
     std::vector<Bounds> own, in_parent;
     std::vector<ConeDirs> cones;  // per object, in its parent's space
+    std::vector<double> ray_cost;  // per object: cost of taking a ray into its space
     std::vector<std::vector<uint32_t>> kids;
     std::vector<int32_t> leaf_id;  // per object: its number among the leaves in the reference's (depth-first) order
     std::vector<RtNode> *nodes = nullptr;  // the table being emitted
@@ -194,6 +195,14 @@ struct Builder {
             next = idx + 1;
         }
         const Matrix4 T = Matrix4::from_array(o.transformation);
+        {
+            // (scale and translation only, by the forward matrix: its inverse then has the same structure)
+            bool diagonal = true;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c)
+                    if (r != c && T.d[r][c] != 0.0) diagonal = false;
+            ray_cost[idx] = diagonal ? COST_RAY_DIAGONAL : COST_RAY_GENERAL;
+        }
         if (o.kind == RT_CONE || (o.kind == RT_GROUP && !kids[idx].empty())) {
             const auto Tinv = T.inverse();
             if (o.kind == RT_CONE) {
@@ -250,15 +259,27 @@ struct Builder {
     // a ray meets first in space it then also meets first in the table, its closest hit is found early, and the
     // range-skip boxes behind that hit are rejected by distance.  Members without finite bounds (planes, unlimited
     // cylinders and cones: no box can hold them) stay in front, in the reference's order.
+    struct Plan {
+        int32_t outer;  // the tree node whose box was tested last before this one is reached; -1: the list's own bounds
+        bool node;      // this tree node gets a range-skip node then
+        double cost;    // expected cost of everything below, the node's own test included
+    };
     struct OrderNode {
         int32_t left = -1, right = -1;
         uint32_t member = 0, count = 0;
         int axis = 0;
+        Bounds box = Bounds::empty();  // around the members, in the list's space
+        double work = 0.0;             // cost of testing every member once
+        bool can_node = false;         // a conservative range-skip box exists (skipbox, dirs)
+        double skipbox[6] = {0, 0, 0, 0, 0, 0};
+        ConeDirs dirs;
+        std::vector<Plan> plans;
     };
     struct ListLayout {
         std::vector<uint32_t> unbounded;
         std::vector<OrderNode> tree;
         int32_t root = -1;
+        double walk = 0.0;  // expected cost of walking the list once
     };
     std::vector<ListLayout> layouts;  // per object (groups: their children); the last one is the world's own list
 
@@ -271,23 +292,41 @@ struct Builder {
         const Bounds &bb = in_parent[k];
         return axis == 0 ? bb.min.x + bb.max.x : axis == 1 ? bb.min.y + bb.max.y : bb.min.z + bb.max.z;
     }
+    static double surface(const Bounds &b) {
+        const double x = b.max.x - b.min.x, y = b.max.y - b.min.y, z = b.max.z - b.min.z;
+        return x * y + y * z + z * x;
+    }
+    double member_cost(uint32_t m) const {
+        const int kind = world.objects[m].kind;
+        return COST_RECORD + ray_cost[m] + (kind == RT_GROUP ? COST_BOUNDS + layouts[m].walk : COST_LEAF[kind]);
+    }
+    // The order tree over the members [lo, hi) of a list.  The cut is the one, along any of the three axes (members
+    // sorted by their centres), for which the two sides' boxes are smallest for what they hold: surface of the side's
+    // box times the cost of testing its members, summed over both sides.  Long lists are not cut closer than an eighth from either
+    // end, which bounds the depth of the tree.
     int32_t build_tree(ListLayout &L, std::vector<uint32_t>::iterator lo, std::vector<uint32_t>::iterator hi) {
         const int32_t at = (int32_t)L.tree.size();
         L.tree.emplace_back();
         const size_t n = (size_t)(hi - lo);
-        L.tree[(size_t)at].count = (uint32_t)n;
-        if (n == 1) {
-            L.tree[(size_t)at].member = *lo;
-            return at;
+        {
+            OrderNode &t = L.tree[(size_t)at];
+            t.count = (uint32_t)n;
+            const std::vector<uint32_t> members(lo, hi);
+            for (uint32_t m : members) {
+                t.box = t.box.merge(in_parent[m]);
+                t.work += member_cost(m);
+            }
+            t.can_node = skip_box(members, t.skipbox, t.dirs);
+            if (n == 1) {
+                t.member = *lo;
+                return at;
+            }
         }
-        static const size_t use_sah = env_size("RT_SAH", 1);
         int axis = 0;
-        auto mid = lo + (std::ptrdiff_t)(n / 2);
-        if (use_sah && n >= 3) {
-            // The cut, along any of the three axes (members sorted by their centres), for which the two sides' boxes
-            // are smallest for what they hold: surface of the side's box times its member count, summed over both.
+        size_t best_at = n / 2;
+        if (n >= 3) {
+            const size_t margin = n >= 16 ? n / 8 : 1;
             double best = INFINITY;
-            size_t best_at = n / 2;
             std::vector<uint32_t> sorted(lo, hi), best_order;
             std::vector<double> right_area(n);
             for (int a = 0; a < 3; ++a) {
@@ -296,48 +335,33 @@ struct Builder {
                     return cx < cy || (cx == cy && x < y);
                 });
                 Bounds acc = Bounds::empty();
+                double work = 0.0;
                 for (size_t k = n; k-- > 1;) {
                     acc = acc.merge(in_parent[sorted[k]]);
-                    right_area[k] = surface(acc);
+                    work += member_cost(sorted[k]);
+                    right_area[k] = surface(acc) * work;
                 }
                 acc = Bounds::empty();
+                work = 0.0;
+                bool better = false;
                 for (size_t k = 1; k < n; ++k) {
                     acc = acc.merge(in_parent[sorted[k - 1]]);
-                    const double cost = surface(acc) * (double)k + right_area[k] * (double)(n - k);
-                    if (cost < best) {
+                    work += member_cost(sorted[k - 1]);
+                    const double cost = surface(acc) * work + right_area[k];
+                    if (k >= margin && n - k >= margin && cost < best) {
                         best = cost;
                         best_at = k;
                         axis = a;
-                        best_order.clear();
+                        better = true;
                     }
                 }
-                if (best_order.empty() && axis == a) best_order = sorted;
+                if (better || best_order.empty()) best_order = sorted;  // (no finite cost anywhere: the middle of the x order)
             }
-            if (!best_order.empty() && std::isfinite(best)) {
-                std::copy(best_order.begin(), best_order.end(), lo);
-                mid = lo + (std::ptrdiff_t)best_at;
-            } else {
-                axis = -1;
-            }
-        } else {
-            axis = -1;
+            std::copy(best_order.begin(), best_order.end(), lo);
+        } else if (centre(*lo, 0) > centre(*(lo + 1), 0)) {
+            std::iter_swap(lo, lo + 1);
         }
-        if (axis < 0) {
-            double cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-            for (auto it = lo; it != hi; ++it)
-                for (int a = 0; a < 3; ++a) {
-                    cmin[a] = std::fmin(cmin[a], centre(*it, a));
-                    cmax[a] = std::fmax(cmax[a], centre(*it, a));
-                }
-            axis = 0;
-            for (int a = 1; a < 3; ++a)
-                if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
-            mid = lo + (std::ptrdiff_t)(n / 2);
-            std::nth_element(lo, mid, hi, [&](uint32_t x, uint32_t y) {
-                const double cx = centre(x, axis), cy = centre(y, axis);
-                return cx < cy || (cx == cy && x < y);
-            });
-        }
+        const auto mid = lo + (std::ptrdiff_t)best_at;
         const int32_t l = build_tree(L, lo, mid), r = build_tree(L, mid, hi);
         OrderNode &t = L.tree[(size_t)at];
         t.axis = axis;
@@ -345,10 +369,39 @@ struct Builder {
         t.right = r;
         return at;
     }
+    // Which tree nodes become range-skip nodes: expected cost, for a wave that has just passed the box of tree node
+    // `outer`, of everything below `node` -- with a range-skip node here (its test, then the rest for the share of
+    // waves that pass it: the ratio of the two boxes' surfaces) or without (the rest, for every wave).  A member on
+    // its own is treated the same way: a node in front of it pays when its box is small inside the outer one and
+    // its own test is long.
+    double plan(ListLayout &L, int32_t node, int32_t outer) {
+        {
+            const OrderNode &t = L.tree[(size_t)node];
+            for (const Plan &e : t.plans)
+                if (e.outer == outer) return e.cost;
+        }
+        const double outer_area = surface(L.tree[(size_t)(outer < 0 ? L.root : outer)].box);
+        const double area = surface(L.tree[(size_t)node].box);
+        double pass = area / outer_area;
+        if (!(pass < 1.0)) pass = 1.0;  // (also when the ratio is not a number: flat or unbounded boxes)
+        const bool leaf = L.tree[(size_t)node].count == 1;
+        const int32_t l = L.tree[(size_t)node].left, r = L.tree[(size_t)node].right;
+        double without = leaf ? L.tree[(size_t)node].work : plan(L, l, outer) + plan(L, r, outer);
+        double with = INFINITY;
+        if (L.tree[(size_t)node].can_node && node != outer && pass < 1.0)
+            with = COST_BOX + pass * (leaf ? L.tree[(size_t)node].work : plan(L, l, node) + plan(L, r, node));
+        const bool here = with < without;
+        L.tree[(size_t)node].plans.push_back(Plan{outer, here, here ? with : without});
+        return here ? with : without;
+    }
     void build_layout(ListLayout &L, const std::vector<uint32_t> &list) {
         std::vector<uint32_t> bounded;
         for (uint32_t k : list) (ordered && finite_bounds(k) ? bounded : L.unbounded).push_back(k);
-        if (!bounded.empty()) L.root = build_tree(L, bounded.begin(), bounded.end());
+        for (uint32_t k : L.unbounded) L.walk += member_cost(k);
+        if (bounded.empty()) return;
+        L.tree.reserve(2 * bounded.size());
+        L.root = build_tree(L, bounded.begin(), bounded.end());
+        L.walk += plan(L, L.root, -1);
         if (bounded.size() >= 2) out.reordered = true;
     }
     // The two halves of a split in the order a table for octant `oct` lists them (bit a of oct: rays travel towards -a)
@@ -357,91 +410,31 @@ struct Builder {
         first = flip ? t.right : t.left;
         second = flip ? t.left : t.right;
     }
-    void collect(const ListLayout &L, int32_t node, unsigned oct, std::vector<uint32_t> &members) const {
-        const OrderNode &t = L.tree[(size_t)node];
-        if (t.count == 1) {
-            members.push_back(t.member);
-            return;
-        }
-        int32_t a, b;
-        halves(t, oct, a, b);
-        collect(L, a, oct, members);
-        collect(L, b, oct, members);
-    }
 
-    // Emits the members below `node` of a list's order tree, wrapping sub-ranges of long lists in range-skip nodes:
-    // lists longer than SKIP_MIN_LIST are cut in two or (above 4 runs) four parts, recursively, until a part has at
-    // most SKIP_RUN members; every part of two or more members gets a node.
-    static double surface(const Bounds &b) {
-        const double x = b.max.x - b.min.x, y = b.max.y - b.min.y, z = b.max.z - b.min.z;
-        return x * y + y * z + z * x;
-    }
-    Bounds around(const std::vector<uint32_t> &members) const {
-        Bounds u = Bounds::empty();
-        for (uint32_t k : members) u = u.merge(in_parent[k]);
-        return u;
-    }
-    // `outer`: surface of the box (range-skip node or the list's own bounds) tested last before these members.
-    bool emit_tree(const ListLayout &L, int32_t node, uint32_t depth, unsigned oct, bool whole_list, double outer) {
+    // Emits the members below `node` of a list's order tree with the range-skip nodes plan() chose.
+    bool emit_tree(const ListLayout &L, int32_t node, uint32_t depth, unsigned oct, int32_t outer) {
         const OrderNode &t = L.tree[(size_t)node];
-        const size_t n = t.count;
-        if (n <= (whole_list ? SKIP_MIN_LIST : SKIP_RUN)) {
-            std::vector<uint32_t> members;
-            collect(L, node, oct, members);
-            for (uint32_t m : members) {
-                // A member whose own test is expensive next to a box test gets a node of its own in front: a group
-                // (ray transform + six divisions) always, a cube, cylinder or cone (ray transform + a long
-                // intersection routine) when the box test is likely to fail.
-                const int kind = world.objects[m].kind;
-                double box[6];
-                ConeDirs dirs;
-                const bool worth = kind == RT_GROUP || surface(in_parent[m]) * 100.0 < outer * (double)SKIP_WRAP_PERCENT;
-                const bool wrap = ordered && kind != RT_SPHERE && kind != RT_PLANE && worth && skip_box({m}, box, dirs);
-                const size_t ni = nodes->size();
-                if (wrap) push_skip(box, dirs, depth);
-                if (!emit(m, depth, oct)) return false;
-                if (wrap) (*nodes)[ni].skip = (int32_t)nodes->size();
-            }
-            return true;
+        bool here = false;
+        for (const Plan &e : t.plans)
+            if (e.outer == outer) here = e.node;
+        const size_t ni = nodes->size();
+        if (here) push_skip(t.skipbox, t.dirs, depth);
+        const int32_t inner = here ? node : outer;
+        if (t.count == 1) {
+            if (!emit(t.member, depth, oct)) return false;
+        } else {
+            int32_t a, b;
+            halves(t, oct, a, b);
+            if (!emit_tree(L, a, depth, oct, inner) || !emit_tree(L, b, depth, oct, inner)) return false;
         }
-        int32_t half[2];
-        halves(t, oct, half[0], half[1]);
-        std::vector<int32_t> parts;
-        for (int32_t h : half) {
-            const OrderNode &c = L.tree[(size_t)h];
-            if (n > SKIP_WIDE && c.count >= 2) {
-                int32_t a, b;
-                halves(c, oct, a, b);
-                parts.push_back(a);
-                parts.push_back(b);
-            } else {
-                parts.push_back(h);
-            }
-        }
-        for (int32_t part : parts) {
-            std::vector<uint32_t> members;
-            collect(L, part, oct, members);
-            double box[6];
-            ConeDirs dirs;
-            if (members.size() >= 2 && surface(around(members)) * 100.0 < outer * (double)SKIP_PART_PERCENT && skip_box(members, box, dirs)) {
-                const size_t ni = nodes->size();
-                push_skip(box, dirs, depth);
-                if (!emit_tree(L, part, depth, oct, false, surface(around(members)))) return false;
-                (*nodes)[ni].skip = (int32_t)nodes->size();
-            } else if (!emit_tree(L, part, depth, oct, false, outer)) {
-                return false;
-            }
-        }
+        if (here) (*nodes)[ni].skip = (int32_t)nodes->size();
         return true;
     }
 
     bool emit_list(const ListLayout &L, uint32_t depth, unsigned oct) {
         for (uint32_t m : L.unbounded)
             if (!emit(m, depth, oct)) return false;
-        if (L.root < 0) return true;
-        std::vector<uint32_t> members;
-        collect(L, L.root, oct, members);
-        return emit_tree(L, L.root, depth, oct, true, surface(around(members)));
+        return L.root < 0 || emit_tree(L, L.root, depth, oct, -1);
     }
 
     // Appends object `idx` and its subtree.
@@ -519,6 +512,7 @@ int flatten_world(const rt_world_desc &world, FlatScene &out, std::string &err) 
     b.in_parent.resize(world.n_objects);
     b.kids.resize(world.n_objects);
     b.cones.resize(world.n_objects);
+    b.ray_cost.assign(world.n_objects, COST_RAY_GENERAL);
     b.leaf_id.assign(world.n_objects, -1);
     std::vector<uint32_t> top;
     uint32_t idx = 0;
@@ -540,7 +534,7 @@ int flatten_world(const rt_world_desc &world, FlatScene &out, std::string &err) 
     for (uint32_t k = 0; k < world.n_objects; ++k) any_group = any_group || world.objects[k].kind == RT_GROUP;
     b.ordered = any_group || top.size() > SKIP_MIN_LIST;
     b.layouts.resize((size_t)world.n_objects + 1);
-    for (uint32_t k = 0; k < world.n_objects; ++k)
+    for (uint32_t k = world.n_objects; k-- > 0;)  // children before their parents: a group's cost includes its list's
         if (world.objects[k].kind == RT_GROUP) b.build_layout(b.layouts[k], b.kids[k]);
     b.build_layout(b.layouts[world.n_objects], top);
     // One table per octant of ray directions (an ordered world), or the one table in the reference's order.  Octants
