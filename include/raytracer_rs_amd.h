@@ -118,7 +118,12 @@ typedef struct rt_stats {
 } rt_stats;
 
 typedef struct rt_render_opts {
-    uint32_t row_begin, row_end; /* rows [row_begin, row_end) of the frame; both 0 = the whole frame */
+    uint32_t row_begin, row_end; /* rows [row_begin, row_end) of the frame; both 0 = the whole frame.  A pixel comes
+                                    out bit-identical to the whole frame's when the range lies on the 8-row grid the
+                                    kernels tile the frame with (row_begin, and row_end unless it is the frame's last
+                                    row, multiples of 8; likewise band_rows below); other ranges may differ from it in
+                                    the last bits of a colour in worlds with groups or long object lists, where the
+                                    lanes of a tile share rays and a pixel's terms are then summed in another order */
     int32_t max_depth;           /* recursion budget per pixel (world.rs:117 `remaining`).  0 = RT_DEFAULT_DEPTH, so that
                                     zeroed options mean the reference's behaviour; a budget of zero itself (no
                                     reflection or refraction rays at all) is max_depth = 0 with RT_RENDER_EXACT_DEPTH */

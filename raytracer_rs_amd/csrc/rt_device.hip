@@ -920,6 +920,15 @@ __device__ __forceinline__ void ray_for_pixel(const RtCameraDev &cam, unsigned p
 // next ray from the stack.  All lanes of a wave are thus always in the same phase: the two traversals never mix
 // scattered radiance rays with the coherent shadow rays, and the shading code runs once per round.  A lane whose
 // ray missed simply sits out the shadow traversal.
+__device__ __forceinline__ double readlane_double(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+#ifndef RT_SHARE_MIN_IDLE
+#define RT_SHARE_MIN_IDLE 24
+#endif
+constexpr int SHARE_MIN_IDLE = RT_SHARE_MIN_IDLE;
+constexpr int SHARE_MAX = 48;  // rays handed between lanes per round: 8 values x 48 = the 6 x 64 doubles that park traversal rays
+
 template <int NEST, bool STATS, bool TIES = ANY_ORDER<NEST>>
 __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 rd, int remaining0, V3 &acc,
                                          Ctr<STATS> &ctr) {
@@ -927,6 +936,11 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
     double w = 1.0;
     int remaining = remaining0;
     acc = mk(0.0, 0.0, 0.0);
+    // The kernels for scenes with groups share rays between lanes: a lane whose own pixel has no ray left takes a
+    // pending ray off another lane's stack (below), so a ray carries the lane its colour belongs to.
+    constexpr bool SHARE = NEST > 0;
+    const int lane = (int)(threadIdx.x & 63u);
+    int owner = lane;
 
     // Pending rays (origin, direction, weight, remaining budget), last in first out.  The newest one lives in
     // registers (nx_*, valid while nx_rem >= 0); below it, the first LDS_LEVELS entries live in the workgroup's LDS
@@ -946,6 +960,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
     // registers more than a pop needs to be free of a memory round trip (with the copy: 21 spilled VGPRs, 1-2 % slower).
     constexpr bool REG_TOP = NEST == 0;
     auto push = [&](V3 po, V3 pd, double pw, int prem) {
+        if constexpr (SHARE) prem |= owner << 8;
         if constexpr (!REG_TOP) {
             nx_o = po;
             nx_d = pd;
@@ -990,6 +1005,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
         RT_TIC(tm1);
         const bool shade = have && best.leaf >= 0 && S.light.has_light;  // else black: world.rs:124, world.rs:86-89
         V3 acc_lit = acc;         // the sum if the hit is not in shadow (acc: if it is)
+        V3 term = mk(0.0, 0.0, 0.0);  // (SHARE) this ray's term of its owner's sum
         V3 sro = ro, srd = rd;    // the shadow ray
         double h_dist = 0.0;
         int h_flags = 0;
@@ -1006,8 +1022,13 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
 
             V3 shadowed, lit;
             lighting<STATS>(s, S.light, point, object_point, eye, normal, shadowed, lit, h_flags, ctr);
-            acc_lit = acc + lit * w;
-            acc = acc + shadowed * w;
+            if constexpr (SHARE) {  // the two candidate terms; the sum is formed in the owner's lane, below
+                acc_lit = lit * w;
+                term = shadowed * w;
+            } else {
+                acc_lit = acc + lit * w;
+                acc = acc + shadowed * w;
+            }
 
             const double reflectivity = s->reflectivity;
             const double transparency = s->transparency;
@@ -1082,10 +1103,24 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
         if (__ballot(shade) != 0ull) {
             const bool in_shadow = occluded<NEST, STATS>(S, sro, srd, shade, h_dist, ctr);  // world.rs:145-148
             if (shade && !in_shadow) {
-                acc = acc_lit;
+                if constexpr (SHARE) term = acc_lit;
+                else acc = acc_lit;
                 if (STATS) {
                     if (h_flags & 1) ctr.add(C_LIT);
                     if (h_flags & 2) ctr.add(C_SPECULAR);
+                }
+            }
+            if constexpr (SHARE) {
+                // Every term goes to the sum of the lane that owns its ray: a lane's own first, then the others' in
+                // lane order, one at a time -- a fixed order, so a frame comes out the same every time.
+                if (shade && owner == lane) acc = acc + term;
+                unsigned long long foreign = __ballot(shade && owner != lane);
+                while (foreign != 0ull) {
+                    const int j = __builtin_ctzll(foreign);
+                    foreign &= foreign - 1ull;
+                    const int to = __builtin_amdgcn_readlane(owner, j);
+                    const V3 t = mk(readlane_double(term.x, j), readlane_double(term.y, j), readlane_double(term.z, j));
+                    if (lane == to) acc = acc + t;
                 }
             }
         }
@@ -1123,6 +1158,65 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
                 w = nx_w;
                 remaining = nx_rem;
                 nx_rem = -1;
+            }
+            if constexpr (SHARE) {
+                owner = remaining >> 8;
+                remaining &= 0xff;
+            }
+        }
+        if constexpr (SHARE) {
+            // Lanes left without a ray take one from lanes that still hold pending ones: the k-th idle lane gets
+            // the top of the k-th such lane's stack, handed over through the LDS that parks traversal rays (idle
+            // between traversals).  An idle lane's stack is empty, so the ray it receives starts a stack of at most
+            // STACK_MAX entries there like any other ray.  Which lane gets which ray depends only on the shape of
+            // the ray trees, so the counting kernel and the plain one make the same moves.
+            const unsigned long long idle = __ballot(!have);
+            const unsigned long long rich = __ballot(sp > 0);
+            if (__popcll(idle) >= SHARE_MIN_IDLE && rich != 0ull) {
+                int n = __popcll(idle) < __popcll(rich) ? __popcll(idle) : __popcll(rich);
+                n = n < SHARE_MAX ? n : SHARE_MAX;
+                const int give = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(rich >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)rich, 0u));
+                const int take = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                double *mail = ray_stack_lds + S.park_base;  // [8][SHARE_MAX]
+                if (sp > 0 && give < n) {
+                    sp--;
+                    V3 go, gd;
+                    double gw;
+                    int grem;
+                    if (sp < LDS_LEVELS) {
+                        const double *e = lds + sp * (8 * 64);
+                        go = mk(e[0 * 64], e[1 * 64], e[2 * 64]);
+                        gd = mk(e[3 * 64], e[4 * 64], e[5 * 64]);
+                        gw = e[6 * 64];
+                        grem = __double2loint(e[7 * 64]);
+                    } else {
+                        const int d = sp - LDS_LEVELS;
+                        go = mk(stk[d][0], stk[d][1], stk[d][2]);
+                        gd = mk(stk[d][3], stk[d][4], stk[d][5]);
+                        gw = stk[d][6];
+                        grem = stk_rem[d];
+                    }
+                    double *m = mail + give;
+                    m[0 * SHARE_MAX] = go.x; m[1 * SHARE_MAX] = go.y; m[2 * SHARE_MAX] = go.z;
+                    m[3 * SHARE_MAX] = gd.x; m[4 * SHARE_MAX] = gd.y; m[5 * SHARE_MAX] = gd.z;
+                    m[6 * SHARE_MAX] = gw;
+                    m[7 * SHARE_MAX] = __hiloint2double(0, grem);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (!have && take < n) {
+                    const double *m = mail + take;
+                    ro = mk(m[0 * SHARE_MAX], m[1 * SHARE_MAX], m[2 * SHARE_MAX]);
+                    rd = mk(m[3 * SHARE_MAX], m[4 * SHARE_MAX], m[5 * SHARE_MAX]);
+                    w = m[6 * SHARE_MAX];
+                    const int meta = __double2loint(m[7 * SHARE_MAX]);
+                    owner = meta >> 8;
+                    remaining = meta & 0xff;
+                    have = true;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the parked-ray area is free again before the next traversal writes it
             }
         }
 #ifdef RT_TIMING

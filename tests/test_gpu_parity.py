@@ -974,7 +974,12 @@ def _full_size_checks(orc, scene, cam, ocam, oworld, n_sample_bands, band_rows=4
         del ref
         _, pst = scene.render(cam, rows=(y0, y0 + band_rows), stats=True, out=plain)  # rows of the whole-frame buffer
         counters_equal(pst, oc)
-        assert np.array_equal(plain[y0:y0 + band_rows], img[y0:y0 + band_rows])
+        # Rows that do not start and end on the 8-row tile grid put a pixel in a tile with other neighbours; in scenes
+        # with groups lanes hand rays to each other, so the terms of a pixel's sum may then be added in another order.
+        assert np.abs(plain[y0:y0 + band_rows] - img[y0:y0 + band_rows]).max() <= 1e-13
+        t0 = y0 // 8 * 8
+        scene.render(cam, rows=(t0, t0 + 8), out=plain)
+        assert np.array_equal(plain[t0:t0 + 8], img[t0:t0 + 8])
     plain.fill(0.0)
     for r in range(8):
         scene.render(cam, bands=(16, r, 8), out=plain)
