@@ -62,13 +62,16 @@ constexpr int STACK_MAX = RT_MAX_DEPTH + 1;  // in memory: at most one parked ra
 #ifndef RT_NEST_LDS_LEVELS
 #define RT_NEST_LDS_LEVELS 1
 #endif
+#ifndef RT_SHARE_FLAT
+#define RT_SHARE_FLAT 0
+#endif
 template <int NEST>
 constexpr int LDS_LEVELS = NEST > 0 ? RT_NEST_LDS_LEVELS : 2;
 // Dynamic LDS of every kernel here, per wave of the workgroup: the LDS levels of the pending-ray stack (kernels that
 // run radiance()), then the slot in which a traversal parks the level-1 ray while it walks a nested group (kernels
 // built for scenes with groups: 6 x 64 doubles = 3 KB).  11 KB per wave for the render kernel of a scene with groups.
 template <int NEST, bool RADIANCE>
-constexpr unsigned LDS_WAVE_DOUBLES = ((RADIANCE ? LDS_LEVELS<NEST> * 8 : 0) + (NEST > 0 ? 6 : 0)) * 64;
+constexpr unsigned LDS_WAVE_DOUBLES = ((RADIANCE ? LDS_LEVELS<NEST> * 8 : 0) + (NEST > 0 ? 6 : (RADIANCE && RT_SHARE_FLAT) ? 2 : 0)) * 64;
 template <int NEST, bool RADIANCE>
 constexpr size_t lds_bytes(unsigned block) { return (size_t)(block / 64) * LDS_WAVE_DOUBLES<NEST, RADIANCE> * sizeof(double); }
 extern __shared__ double ray_stack_lds[];
@@ -927,7 +930,6 @@ __device__ __forceinline__ double readlane_double(double v, int lane) {
 #define RT_SHARE_MIN_IDLE 24
 #endif
 constexpr int SHARE_MIN_IDLE = RT_SHARE_MIN_IDLE;
-constexpr int SHARE_MAX = 48;  // rays handed between lanes per round: 8 values x 48 = the 6 x 64 doubles that park traversal rays
 
 template <int NEST, bool STATS, bool TIES = ANY_ORDER<NEST>>
 __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 rd, int remaining0, V3 &acc,
@@ -938,7 +940,8 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
     acc = mk(0.0, 0.0, 0.0);
     // The kernels for scenes with groups share rays between lanes: a lane whose own pixel has no ray left takes a
     // pending ray off another lane's stack (below), so a ray carries the lane its colour belongs to.
-    constexpr bool SHARE = NEST > 0;
+    constexpr bool SHARE = NEST > 0 || RT_SHARE_FLAT;
+    constexpr int SHARE_MAX = NEST > 0 ? 48 : 16;  // rays handed over per round: 8 values x 48 fill the 6 x 64 doubles that park traversal rays
     const int lane = (int)(threadIdx.x & 63u);
     int owner = lane;
 
