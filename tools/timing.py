@@ -34,8 +34,26 @@ def main():
         rows_rendered = sum(min(bands[0], h - y) for y in range(bands[1] * bands[0], h, bands[0] * bands[2]))
     n_waves = ((w + 7) // 8) * ((rows_rendered + 7) // 8)
     buf = np.zeros((n_waves, 6), dtype=np.uint64)
-    scene.render(cam, bands=bands)
-    img, st = scene.render(cam, bands=bands)
+    # one launch per frame, into device memory (rt_render cuts a frame into groups of rows, each a launch of its own
+    # whose waves would overwrite each other's records)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    frame = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(frame), w * rows_rendered * 3) == 0
+    def launch(**kw):
+        if bands:
+            scene.render_device_bands(cam, frame.value, *bands, quantized=True, **kw)
+        else:
+            scene.render_device(cam, frame.value, quantized=True, **kw)
+
+    for _ in range(3):
+        launch()
+    launch(timed=True)
+    assert hip.hipDeviceSynchronize() == 0
+
+    class _St:
+        kernel_ms = sum(scene.render_times())
+    st = _St()
     lib.rt_debug_timing(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(n_waves))
     m32, m40 = np.uint64(0xFFFFFFFF), np.uint64((1 << 40) - 1)
     trace, shade = (buf[:, 0] & m32).astype(float), (buf[:, 0] >> np.uint64(32)).astype(float)
