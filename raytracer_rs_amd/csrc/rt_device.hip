@@ -1286,13 +1286,11 @@ __device__ __forceinline__ unsigned quantize_value(double v) {
 // ones.  The estimate comes from the ray through the tile's centre (classify_tiles_kernel); tiles are then counting-
 // sorted by the quarter-octave of the estimate (order_count_kernel, order_scatter_kernel).  Scratch layout, in words:
 //   [0, 128)                 tiles per class           (cleared by classify_tiles_kernel)
-//   [128, 256)               tiles placed so far, per class (cleared likewise); the last word: tiles handed to
-//                            waves that had finished their first one (render_kernel)
+//   [128, 256)               tiles placed so far, per class (cleared likewise)
 //   [256 + 0*n, 256 + 1*n)   the tiles in launch order
 //   [256 + 1*n, 256 + 2*n)   cost estimate per tile
 //   [256 + 2*n, 256 + 3*n)   class per tile
 enum { TILE_CLASSES = 128, TILE_HEADER = 2 * TILE_CLASSES };
-enum { TILE_QUEUE = TILE_HEADER - 1 };  // the place counter of a class no estimate reaches (classes end at 115): tiles handed out beyond the launch's first ones
 enum { RENDER_BLOCK = 64 };  // threads per workgroup of render_kernel
 __device__ __forceinline__ unsigned image_row(const RowMap &rows, unsigned r) {
     return rows.row_begin + (r / rows.band_rows) * rows.band_pitch + (r % rows.band_rows);
@@ -1445,35 +1443,26 @@ __global__ __launch_bounds__(ORDER_BLOCK) void order_scatter_kernel(RowMap rows,
 // traversal's values spilled): their node tables do not fit the scalar cache, the record fetches miss, and a fifth
 // wave to switch to is worth more than the spills cost (chapter_14 at 4K -3 %, the generated scene at 8K -6 %; six
 // and eight waves gain nothing more).
-struct RenderArgs {
-    DeviceScene scene;
-    RtCameraDev cam;
-    RowMap rows;
-    int max_depth;
-    double *rgb;
-    unsigned long long *counters;
-};
 template <bool STATS, int NEST, bool TIES>
 #ifndef RT_NEST_WAVES
 #define RT_NEST_WAVES 5
 #endif
-__device__ __attribute__((noinline)) void render_tile(unsigned tile_in, Ctr<STATS> &ctr) {
-    // (a function of its own, called once per tile: with the tile loop round this body the optimiser moves work out of
-    // the loop and into registers that the traversal needs.  Arguments arrive in vector registers; the tile number is
-    // wave-uniform, and the kernel's arguments are read from the kernel-argument segment, whose address is scalar.)
+__global__ __launch_bounds__(RENDER_BLOCK, NEST > 0 ? RT_NEST_WAVES : 4) void render_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth,
+                                                     double *__restrict__ rgb, unsigned long long *counters) {
     const unsigned lane = threadIdx.x & 63;
-    const unsigned tile = (unsigned)uniform((int)tile_in);
-    const RenderArgs &args = *(const RenderArgs *)(const RenderArgs RT_CONSTANT_AS *)__builtin_amdgcn_kernarg_segment_ptr();
-    const RtCameraDev &cam = args.cam;
-    const RowMap &rows = args.rows;
-    const int max_depth = args.max_depth;
-    double *__restrict__ const rgb = args.rgb;
+    unsigned tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (rows.tile_list) {  // the tile this wave renders: the launch order lists the expensive ones first
+        if (tile >= rows.n_tiles) return;
+        tile = ((const unsigned RT_CONSTANT_AS *)rows.tile_list)[TILE_HEADER + tile];
+    }
     const unsigned tiles_x = (cam.hsize + 7) >> 3;
     const unsigned x = (tile % tiles_x) * 8 + (lane & 7);
     const unsigned r = (tile / tiles_x) * 8 + (lane >> 3);  // row in the packed output
     const unsigned y = image_row(rows, r);
     const bool valid = x < cam.hsize && r < rows.n_rows && y < rows.row_end;
-    SceneK S = scene_k<NEST, true>(args.scene, max_depth);
+    SceneK S = scene_k<NEST, true>(scene, max_depth);
+    Ctr<STATS> ctr;
+    ctr.clear();
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     if (valid) {
         ray_for_pixel(cam, x, y, ro, rd);
@@ -1527,33 +1516,7 @@ __device__ __attribute__((noinline)) void render_tile(unsigned tile_in, Ctr<STAT
         rgb[idx + 1] = acc.y;
         rgb[idx + 2] = acc.z;
     }
-}
-
-// With a launch order the launch is only as many waves as the GPU holds at once, and a wave that has finished a tile
-// takes the next one in the order from a counter in the order's header (word TILE_QUEUE, zero at launch: the first
-// gridDim.x tiles need no counter), so no wave slot stands empty while a workgroup is being set up for it.  The
-// counter is asked for the tile after this one before the tile is rendered and read afterwards.  Without a launch
-// order: one workgroup per tile, in row-major order.
-template <bool STATS, int NEST, bool TIES>
-__global__ __launch_bounds__(RENDER_BLOCK, NEST > 0 ? RT_NEST_WAVES : 4) void render_kernel(RenderArgs args) {
-    const unsigned lane = threadIdx.x & 63;
-    Ctr<STATS> ctr;
-    ctr.clear();
-    const unsigned n_tiles = args.rows.n_tiles;
-    const unsigned *const list = args.rows.tile_list;
-    unsigned turn = blockIdx.x;  // (one wave per workgroup)
-    while (turn < n_tiles) {
-        unsigned tile = turn;
-        unsigned ticket = 0;
-        if (list) {
-            tile = ((const unsigned RT_CONSTANT_AS *)list)[TILE_HEADER + turn];
-            if (lane == 0) ticket = atomicAdd(const_cast<unsigned *>(list) + TILE_QUEUE, 1u);
-        }
-        render_tile<STATS, NEST, TIES>(tile, ctr);
-        if (!list) break;
-        turn = gridDim.x + (unsigned)uniform((int)ticket);
-    }
-    flush_counters<STATS>(ctr, args.counters);
+    flush_counters<STATS>(ctr, counters);
 }
 
 template <bool STATS, int NEST>
@@ -1830,8 +1793,7 @@ inline unsigned blocks_for(unsigned n) { return (n + 255u) / 256u; }
 template <bool STATS>
 static void launch_render_nest(int nest, dim3 grid, unsigned block, hipStream_t stream, const DeviceScene &scene, const RtCameraDev &camera,
                                const RowMap &rows, int max_depth, double *rgb, unsigned long long *counters) {
-    const RenderArgs args{scene, camera, rows, max_depth, rgb, counters};
-#define RT_LAUNCH(N, T) render_kernel<STATS, N, T><<<grid, block, lds_bytes<N, true>(block), stream>>>(args)
+#define RT_LAUNCH(N, T) render_kernel<STATS, N, T><<<grid, block, lds_bytes<N, true>(block), stream>>>(scene, camera, rows, max_depth, rgb, counters)
     if (nest == 0) {
         RT_LAUNCH(0, false);
         return;
@@ -1841,21 +1803,6 @@ static void launch_render_nest(int nest, dim3 grid, unsigned block, hipStream_t 
     if (STATS || scene.any_order != 0) RT_LAUNCH(1, true);
     else RT_LAUNCH(1, false);
 #undef RT_LAUNCH
-}
-
-// Waves of the render kernel that the current device holds at once (0: unknown)
-static unsigned wave_slots(bool nested) {
-    static std::mutex mutex;
-    static int cus[64] = {};
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return 0;
-    std::lock_guard<std::mutex> lock(mutex);
-    if (cus[device] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) return 0;
-        cus[device] = n;
-    }
-    return (unsigned)cus[device] * 4u * (nested ? RT_NEST_WAVES : 4u);
 }
 
 size_t render_scratch_words(uint32_t hsize, uint32_t n_rows) {
@@ -1887,15 +1834,8 @@ hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, co
         hipError_t e = hipEventRecord(marks[1], stream);
         if (e != hipSuccess) return e;
     }
-    // One wave per workgroup.  With a launch order there are as many workgroups as the GPU holds at once and each goes
-    // on taking tiles (render_kernel); otherwise one per tile.
-    unsigned n_groups = rows.n_tiles;
-    if (rows.tile_list) {
-        unsigned resident = wave_slots(scene.max_nesting > 0);
-        if (const char *e = getenv("RT_PERSIST_PERCENT")) resident = (unsigned)((unsigned long long)resident * strtoul(e, nullptr, 10) / 100);
-        if (resident != 0 && resident < n_groups) n_groups = resident;
-    }
-    const dim3 grid(n_groups);
+    // One wave per workgroup: a finished wave's slot is refilled at once, without waiting for three more.
+    const dim3 grid(rows.n_tiles);
     const unsigned block = RENDER_BLOCK;
     if (counters)
         launch_render_nest<true>(scene.max_nesting, grid, block, stream, scene, camera, rows, max_depth, rgb, counters);
