@@ -4,6 +4,7 @@
 // RT_ERR_* code with a message); a crash, an out-of-bounds access or undefined behaviour ends the program with a
 // sanitizer report and a non-zero status.  No GPU code is involved: nothing here includes the HIP runtime.
 #include <cstdint>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -68,6 +69,49 @@ void feed(const std::string &text, Tally &tally) {
             std::abort();
         }
     }
+    // ... and the shape of every table: ranges nest (a record's range ends no later than the range it stands in),
+    // a record's level is that of the group it stands in plus one, range-skip boxes are finite and not inverted, and
+    // every table lists every leaf exactly once and the same number of groups
+    auto fail = [](const char *what, size_t k) {
+        std::fprintf(stderr, "table record %zu: %s\n", k, what);
+        std::abort();
+    };
+    const size_t n_tables = per_table ? flat.nodes.size() / per_table : 0;
+    size_t groups_first = 0;
+    for (size_t t = 0; t < n_tables; ++t) {
+        const RtNode *tab = flat.nodes.data() + t * per_table;
+        std::vector<unsigned> seen(flat.surfaces.size(), 0);
+        std::vector<std::pair<size_t, int>> open;  // (end of range, level inside it) of the groups and range-skip nodes around a record
+        size_t groups = 0;
+        for (size_t i = 0; i + 1 < per_table; ++i) {
+            const RtNode &n = tab[i];
+            while (!open.empty() && open.back().first <= i) open.pop_back();
+            const int kind = n.tag & 0xff, level = (n.tag >> RT_NODE_LEVEL_SHIFT) & RT_NODE_LEVEL_MASK;
+            const size_t limit = open.empty() ? per_table - 1 : open.back().first;
+            const int inside = open.empty() ? 0 : open.back().second;
+            if ((size_t)n.skip > limit) fail("its range ends after the range it stands in", t * per_table + i);
+            if (level != inside) fail("its level is not that of the list it stands in", t * per_table + i);
+            if (kind == RT_GROUP) {
+                groups++;
+                open.emplace_back((size_t)n.skip, level + 1);
+            } else if (kind == RT_SKIPBOX) {
+                for (int a = 0; a < 3; ++a)
+                    if (!std::isfinite(n.a[a]) || !std::isfinite(n.a[3 + a]) || n.a[a] > n.a[3 + a]) fail("range-skip box is not a box", t * per_table + i);
+                if ((size_t)n.skip == i + 1) fail("range-skip node in front of nothing", t * per_table + i);
+                open.emplace_back((size_t)n.skip, level);
+            } else {
+                if (kind < RT_SPHERE || kind > RT_CONE) fail("unknown kind", t * per_table + i);
+                if (n.leaf < 0 || (size_t)n.skip != i + 1) fail("leaf without a surface or with a range", t * per_table + i);
+                seen[(size_t)n.leaf]++;
+            }
+        }
+        for (size_t l = 0; l < seen.size(); ++l)
+            if (seen[l] != 1) fail("a leaf is not listed exactly once in a table", l);
+        if (t == 0) groups_first = groups;
+        if (groups != groups_first || groups != flat.n_groups) fail("tables disagree about the number of groups", t);
+    }
+    for (int o = 0; o < 8; ++o)
+        if (n_tables && flat.oct_table[o] >= n_tables) fail("an octant has no table", (size_t)o);
     RtCameraDev dev;
     (void)rt::camera_to_device(cam, dev, err);
 }

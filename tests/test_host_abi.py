@@ -226,7 +226,7 @@ def test_render_rejects_frames_that_are_not_the_canvas_layout(rt):
 
 def test_host_code_under_address_and_ub_sanitizers(tmp_path):
     """The scene-file reader, the loader, the world flattener and the P3 writer, built with -fsanitize=address,undefined
-    (g++; no HIP involved) and fed the nine scene files plus some 2 700 damaged copies of them: every input comes back
+    (g++; no HIP involved) and fed the nine scene files, three generated ones and some 3 600 damaged copies of them: every input comes back
     as a result, and the sanitizers stay silent.  (Its first run found a read through a dangling pointer in the
     integer parser.)"""
     import glob
@@ -239,7 +239,16 @@ def test_host_code_under_address_and_ub_sanitizers(tmp_path):
                             "-static-libasan", "-static-libubsan", "-ffp-contract=off", "-fno-builtin-sin", "-fno-builtin-cos", "-o", exe] + src, capture_output=True, text=True)
     assert build.returncode == 0, build.stderr[-3000:]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:verify_asan_link_order=0")
-    run = subprocess.run([exe] + sorted(glob.glob(os.path.join(GOLDEN, "scenes", "*.toml"))), capture_output=True, text=True, env=env, timeout=300)
+    # besides the reference's scenes: generated ones with long lists, nested groups and every leaf kind, whose order
+    # trees and range-skip plans the driver checks record by record
+    from raytracer_rs_amd import synthetic
+    generated = []
+    for name, text in [("hierarchy", synthetic.large_scene(cells=3, leaves_per_subgroup=30)), ("random_a", synthetic.random_scene(5, n_top=20)),
+                       ("random_b", synthetic.random_scene(11, n_top=40))]:
+        path = tmp_path / (name + ".toml")
+        path.write_text(text)
+        generated.append(str(path))
+    run = subprocess.run([exe] + sorted(glob.glob(os.path.join(GOLDEN, "scenes", "*.toml"))) + generated, capture_output=True, text=True, env=env, timeout=300)
     assert run.returncode == 0, (run.stdout + run.stderr)[-4000:]
     assert "sanitized host run" in run.stdout and "ERROR" not in run.stderr
 
