@@ -253,8 +253,8 @@ struct Builder {
         if (counting) out.n_skip_nodes++;
     }
 
-    // The order tree of a sibling list: the members with finite bounds, split at the median of their centres along
-    // the axis the centres spread most, recursively down to single members.  A table for rays travelling towards
+    // The order tree of a sibling list: the members with finite bounds, cut in two along one of the axes (build_tree
+    // chooses where), recursively down to single members.  A table for rays travelling towards
     // +axis lists the low half of every split first, one for rays travelling towards -axis the high half: whatever
     // a ray meets first in space it then also meets first in the table, its closest hit is found early, and the
     // range-skip boxes behind that hit are rejected by distance.  Members without finite bounds (planes, unlimited
