@@ -673,14 +673,15 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
         // Everything that reads the first 96 bytes of the record happens before the next record is requested.
         V3 lo = co, ld = cd;
         bool shortcut = false;  // a cone below this range-skip node takes the reference's linear shortcut for this ray
+        double qdd = 0.0;
         if (kind == RT_SKIPBOX) {
             if constexpr (!STATS && !B::every) {
                 if (xform == RT_SKIP_CONES) {
                     double m[7];
 #pragma unroll
                     for (int k = 0; k < 7; ++k) m[k] = dwords_to_double(raw.a[2 * k], raw.a[2 * k + 1]);
-                    const double qdd = (m[0] * cd.x + m[1] * cd.y + m[2] * cd.z) * cd.x + (m[1] * cd.x + m[3] * cd.y + m[4] * cd.z) * cd.y +
-                                       (m[2] * cd.x + m[4] * cd.y + m[5] * cd.z) * cd.z;
+                    qdd = (m[0] * cd.x + m[1] * cd.y + m[2] * cd.z) * cd.x + (m[1] * cd.x + m[3] * cd.y + m[4] * cd.z) * cd.y +
+                          (m[2] * cd.x + m[4] * cd.y + m[5] * cd.z) * cd.z;
                     shortcut = !(fabs(qdd) >= m[6]);
                 }
             }
@@ -707,7 +708,20 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
                 }
                 const bool may = active && !settled(best) && (shortcut || box_may_hit(bb, co, inv_d, dmax, hit_limit(best, far)));
                 ctr.visits += may ? 1u : 0u;
-                if (__ballot(may) == 0ull) guess = w.skip;
+                if (__ballot(may) == 0ull) {
+                    guess = w.skip;
+                    if (w.tag & RT_NODE_LOOKAHEAD) {
+                        // The record at `skip` is a range-skip node of this list whose test this record carries
+                        // along: decide it now and go on behind it, or inside it, without fetching it.
+                        const double rb[6] = {(double)__int_as_float(raw.a[14]), (double)__int_as_float(raw.a[15]), (double)__int_as_float(raw.b[0]),
+                                              (double)__int_as_float(raw.b[1]), (double)__int_as_float(raw.b[2]), (double)__int_as_float(raw.b[3])};
+                        const double rbound = dwords_to_double(raw.b[4], raw.b[5]);
+                        const bool rshort = xform == RT_SKIP_CONES && !(fabs(qdd) >= rbound);
+                        const bool rmay = active && !settled(best) && (rshort || box_may_hit(rb, co, inv_d, dmax, hit_limit(best, far)));
+                        ctr.visits += rmay ? 1u : 0u;
+                        guess = __ballot(rmay) != 0ull ? w.skip + 1 : w.leaf;
+                    }
+                }
             }
         }
         asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(ld.x), "+v"(ld.y), "+v"(ld.z));  // the transform is complete

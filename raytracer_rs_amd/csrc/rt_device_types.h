@@ -33,6 +33,7 @@ struct RtNode {
 #define RT_NODE_CLOSED 0x100
 #define RT_NODE_LEVEL_SHIFT 9
 #define RT_NODE_LEVEL_MASK 0x7f
+#define RT_NODE_LOOKAHEAD 0x10000 /* range-skip node: also holds the box of the range-skip node at `skip` (below) */
 // A node kind of this table only (the reference has no such object): a conservative box, in the space of the
 // sibling list it stands in, around the nodes (i, skip).  When no ray of a wave can touch the box the traversal
 // continues at `skip`; otherwise at i + 1, with the same ray.  Its matrix is the identity and it has no leaf.
@@ -41,6 +42,12 @@ struct RtNode {
 // RtNode.xform of a range-skip node: RT_SKIP_CONES when cones lie below it; then inv[0..5] is the symmetric matrix q
 // (xx, xy, xz, yy, yz, zz) and inv[6] the bound: a ray with |d^T q d| < inv[6] must not be culled (see rt_flatten.cpp).
 enum { RT_SKIP_PLAIN = 1, RT_SKIP_CONES = 3 };
+// A range-skip node X whose `skip` record R is a range-skip node of the same sibling list may carry R's test as well
+// (tag bit RT_NODE_LOOKAHEAD): when X rejects the wave, R is what the traversal would fetch and test next, so it is
+// tested at once and the traversal continues at R + 1 or at R's own `skip` without ever fetching R.  Then
+//   inv[7..9]  R's box as six floats (min.xyz, max.xyz), each rounded away from the box's inside
+//   inv[10]    R's bound on |d^T q d| (0 when no cones lie below R); R shares X's q
+//   leaf       R's `skip`
 
 struct RtSurface {
     double inv_world[12];  // rows 0..2 of inverse(world_transformation)

@@ -66,7 +66,7 @@ static size_t env_size(const char *name, size_t fallback) {
 static const size_t SKIP_MIN_LIST = env_size("RT_SKIP_MIN_LIST", 12);  // (developer override for tuning runs)
 // What a wave spends on one record, in vector instructions, the traversal loop's own share included: the figures
 // the choice of range-skip nodes is made with.  (Developer override: RT_COST_BOX.)
-static const double COST_BOX = (double)env_size("RT_COST_BOX", 80);  // a range-skip node: slab test, reach guard, its record
+static const double COST_BOX = (double)env_size("RT_COST_BOX", 60);  // a range-skip node: slab test, reach guard, its record
 static const double COST_RECORD = 20.0;                              // the loop's own work per record
 static const double COST_RAY_GENERAL = 33.0, COST_RAY_DIAGONAL = 9.0;  // the ray into a node's space
 static const double COST_BOUNDS = 75.0;                              // a group's bounds test with its six divisions
@@ -501,6 +501,42 @@ struct Builder {
 
 }  // namespace
 
+// Range-skip nodes whose `skip` record is another range-skip node of the same list take that node's test along
+// (RT_NODE_LOOKAHEAD in rt_device_types.h): about every fifth record a wave fetches is such a successor.
+static void add_lookahead(std::vector<RtNode> &table) {
+    const size_t n = table.size() - 1;  // without the inert record
+    for (size_t i = 0; i < n; ++i) {
+        RtNode &x = table[i];
+        if ((x.tag & 0xff) != RT_SKIPBOX || x.skip <= 0 || (size_t)x.skip >= n) continue;
+        const RtNode &r = table[(size_t)x.skip];
+        if ((r.tag & 0xff) != RT_SKIPBOX) continue;
+        if (((r.tag >> RT_NODE_LEVEL_SHIFT) & RT_NODE_LEVEL_MASK) != ((x.tag >> RT_NODE_LEVEL_SHIFT) & RT_NODE_LEVEL_MASK)) continue;
+        double bound = 0.0;
+        if (r.xform == RT_SKIP_CONES) {  // R's cones must see the directions X's do (one q per node: rt_flatten's ConeDirs)
+            if (x.xform != RT_SKIP_CONES) continue;
+            bool same = true;
+            for (int k = 0; k < 6; ++k) same = same && std::fabs(x.inv[k] - r.inv[k]) <= 1e-9;
+            if (!same) continue;
+            bound = r.inv[6];
+        }
+        float box[6];
+        bool finite = true;
+        for (int k = 0; k < 6; ++k) {
+            float f = (float)r.a[k];
+            if (k < 3 && (double)f > r.a[k]) f = std::nextafterf(f, -INFINITY);
+            if (k >= 3 && (double)f < r.a[k]) f = std::nextafterf(f, INFINITY);
+            finite = finite && std::isfinite(f);
+            box[k] = f;
+        }
+        if (!finite) continue;
+        static_assert(sizeof(box) == 3 * sizeof(double), "six floats fill inv[7..9]");
+        std::memcpy(&x.inv[7], box, sizeof box);
+        x.inv[10] = bound;
+        x.leaf = r.skip;
+        x.tag |= RT_NODE_LOOKAHEAD;
+    }
+}
+
 int flatten_world(const rt_world_desc &world, FlatScene &out, std::string &err) {
     out = FlatScene{};
     if (world.n_objects && !world.objects) {
@@ -551,6 +587,7 @@ int flatten_world(const rt_world_desc &world, FlatScene &out, std::string &err) 
         if (!b.emit_list(b.layouts[world.n_objects], 0, oct)) return b.code;
         t.emplace_back();  // one inert record past the end: the traversal fetches record i+1 while it works on record i
         std::memset(&t.back(), 0, sizeof(RtNode));
+        add_lookahead(t);
         size_t same = tables.size();
         for (size_t k = 0; k < tables.size(); ++k)
             if (tables[k].size() == t.size() && std::memcmp(tables[k].data(), t.data(), t.size() * sizeof(RtNode)) == 0) same = k;

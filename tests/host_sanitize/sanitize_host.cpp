@@ -64,7 +64,8 @@ void feed(const std::string &text, Tally &tally) {
         const RtNode &n = flat.nodes[k];
         const size_t local = k % per_table;
         if (local + 1 == per_table) continue;  // the inert trailing record
-        if (n.skip < 0 || (size_t)n.skip >= per_table || (size_t)n.skip <= local || n.leaf >= (int32_t)flat.surfaces.size()) {
+        const bool is_leaf = (n.tag & 0xff) >= RT_SPHERE && (n.tag & 0xff) <= RT_CONE;
+        if (n.skip < 0 || (size_t)n.skip >= per_table || (size_t)n.skip <= local || (is_leaf && n.leaf >= (int32_t)flat.surfaces.size())) {
             std::fprintf(stderr, "node %zu has skip %d / leaf %d outside its tables\n", k, n.skip, n.leaf);
             std::abort();
         }
@@ -98,6 +99,17 @@ void feed(const std::string &text, Tally &tally) {
                 for (int a = 0; a < 3; ++a)
                     if (!std::isfinite(n.a[a]) || !std::isfinite(n.a[3 + a]) || n.a[a] > n.a[3 + a]) fail("range-skip box is not a box", t * per_table + i);
                 if ((size_t)n.skip == i + 1) fail("range-skip node in front of nothing", t * per_table + i);
+                if (n.tag & RT_NODE_LOOKAHEAD) {  // carries the test of the range-skip node at `skip`
+                    const RtNode &r = tab[(size_t)n.skip];
+                    float box[6];
+                    std::memcpy(box, &n.inv[7], sizeof box);
+                    bool holds = (size_t)n.skip + 1 < per_table && (r.tag & 0xff) == RT_SKIPBOX &&
+                                 ((r.tag >> RT_NODE_LEVEL_SHIFT) & RT_NODE_LEVEL_MASK) == level && n.leaf == r.skip &&
+                                 n.inv[10] == (r.xform == RT_SKIP_CONES ? r.inv[6] : 0.0) && (r.xform != RT_SKIP_CONES || n.xform == RT_SKIP_CONES);
+                    for (int a = 0; a < 3 && holds; ++a)
+                        holds = std::isfinite(box[a]) && std::isfinite(box[3 + a]) && (double)box[a] <= r.a[a] && (double)box[3 + a] >= r.a[3 + a];
+                    if (!holds) fail("range-skip node carries a test that is not its successor's", t * per_table + i);
+                }
                 open.emplace_back((size_t)n.skip, level);
             } else {
                 if (kind < RT_SPHERE || kind > RT_CONE) fail("unknown kind", t * per_table + i);
