@@ -151,33 +151,54 @@ def time_config(scene, cam, stream, reps: int, quantized: bool) -> dict:
             "frac": round(flops / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 4), "kernel": kernel_name(scene)}
 
 
-def cpu_baseline(scene_path: str, width: int, height: int, seconds_target: float = 12.0) -> dict:
-    """Times the CPU oracle on evenly spaced rows of the same frame (checker / baseline only)."""
+def cpu_baseline(scene_path, width: int, height: int, seconds_target: float = 12.0, scene_text: str = None) -> dict:
+    """Times the CPU oracle on evenly spaced rows of the same frame (checker / baseline only).  `scene_path` is a
+    scene file; a generated scene comes as `scene_text`."""
     from oracle import oracle as orc
 
-    cam, world = orc.load_scene(scene_path, width, height)
-    world.set_mode(1)  # the reference's own schedule: per-ray inverses, intersection list + sort, one thread
-    # calibrate on 2 rows, then take as many evenly spaced rows as fit the time target
-    c = orc.Counters()
+    import tomli
+
+    def load(w, h):
+        if scene_path:
+            return orc.load_scene(scene_path, w, h)
+        return orc.scene_from_dict(tomli.loads(scene_text), w, h)
+
+    # The reference's own schedule: per-ray inverses, intersection list + sort, one thread.  Calibrate on the middle
+    # row of a 64x smaller frame, then sample rows of the frame itself -- or, when a single row of it would take more
+    # than a quarter of the time target (thousands of objects), of the same picture at a lower resolution.
+    cam, world = load(max(8, width // 64), max(8, height // 64))
+    world.set_mode(1)
     t0 = time.perf_counter()
-    for y in (height // 3, 2 * height // 3):
-        orc.render(cam, world, threads=1, rows=(y, y + 1), counters=c)
-    per_row = (time.perf_counter() - t0) / 2
-    n_rows = int(max(4, min(height, seconds_target / max(per_row, 1e-6))))
-    ys = sorted(set(int((i + 0.5) * height / n_rows) for i in range(n_rows)))
+    orc.render(cam, world, threads=1, rows=(cam.vsize // 2, cam.vsize // 2 + 1), counters=orc.Counters())
+    per_pixel = (time.perf_counter() - t0) / cam.hsize
+    shrink = 1
+    while shrink < 64 and per_pixel * (width // shrink) > seconds_target / 4:
+        shrink *= 2
+    sw, sh = width // shrink, height // shrink
+    cam, world = load(sw, sh)
+    world.set_mode(1)
+    n_rows = int(max(1, min(sh, seconds_target / max(per_pixel * sw, 1e-6))))
+    ys = sorted(set(int((i + 0.5) * sh / n_rows) for i in range(n_rows)))
     c = orc.Counters()
     t0 = time.perf_counter()
     for y in ys:
         orc.render(cam, world, threads=1, rows=(y, y + 1), counters=c)
     dt = time.perf_counter() - t0
-    out = {"value": round(c.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
-           "sample": f"{len(ys)} evenly spaced rows of the {width}x{height} frame ({c.rays} rays, {dt:.1f} s), "
+    of_what = f"the {width}x{height} frame" if shrink == 1 else f"the same picture at {sw}x{sh} (a row of the {width}x{height} frame alone would take {per_pixel * width:.0f} s)"
+    out = {"value": round(c.rays / dt / 1e6, 6), "unit": "Mrays/s", "cores": 1, "kind": "port",
+           "sample": f"{len(ys)} evenly spaced rows of {of_what} ({c.rays} rays, {dt:.1f} s), "
                      f"oracle in reference-equivalent mode (per-ray 4x4 inverses, intersection list + stable sort)"}
+    cam, world = load(width, height)
     # the same arithmetic with inverses cached, all host cores the box gives us
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     world.set_mode(0)
     c2 = orc.Counters()
-    rows2 = (height // 2 - 40, height // 2 + 40)
+    t0 = time.perf_counter()
+    orc.render(cam, world, threads=1, rows=(height // 2, height // 2 + 1), counters=c2)
+    per_row = time.perf_counter() - t0
+    half = int(max(1, min(40, seconds_target * cores / max(per_row, 1e-6) / 2 / 2)))
+    c2 = orc.Counters()
+    rows2 = (height // 2 - half, height // 2 + half)
     t0 = time.perf_counter()
     orc.render(cam, world, threads=cores, rows=rows2, counters=c2)
     dt2 = time.perf_counter() - t0
@@ -449,8 +470,13 @@ def main() -> None:
                     others.append(r)
                     oscene.close()
                 line["other_configs"] = others
-        if not args.no_cpu_baseline and world_size == 1 and scene_path:
-            line["cpu_baseline"] = cpu_baseline(scene_path, W, H)
+        if not args.no_cpu_baseline and world_size == 1:
+            text = None
+            if not scene_path:
+                from raytracer_rs_amd import synthetic
+
+                text = synthetic.large_scene()
+            line["cpu_baseline"] = cpu_baseline(scene_path, W, H, scene_text=text)
         elif world_size == 1:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
