@@ -1348,10 +1348,16 @@ __global__ __launch_bounds__(256) void classify_tiles_kernel(DeviceScene scene, 
                                                              unsigned *__restrict__ scratch) {
     static_assert(TILE_HEADER == 256, "the first workgroup clears the census and the cursors, one word per thread");
     if (blockIdx.x == 0) scratch[threadIdx.x] = 0u;  // read by the kernels that follow this one
-    const unsigned tile = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = tile < rows.n_tiles;
+    // A wave takes an 8x8 block of tiles, not 64 tiles of one row: its 64 centre rays then cross one region of the
+    // scene instead of a strip as wide as the frame, and walk far fewer records between them.
     const unsigned tiles_x = (cam.hsize + 7) >> 3;
-    unsigned x = (tile % tiles_x) * 8 + 4, r = (tile / tiles_x) * 8 + 4;
+    const unsigned tiles_y = (rows.n_tiles + tiles_x - 1) / tiles_x;
+    const unsigned blocks_x = (tiles_x + 7) >> 3;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    const unsigned tx = (wave % blocks_x) * 8 + (lane & 7u), ty = (wave / blocks_x) * 8 + (lane >> 3);
+    const bool valid = tx < tiles_x && ty < tiles_y;
+    const unsigned tile = ty * tiles_x + tx;
+    unsigned x = tx * 8 + 4, r = ty * 8 + 4;
     if (x >= cam.hsize) x = cam.hsize - 1;
     if (r >= rows.n_rows) r = rows.n_rows - 1;
     SceneK S = scene_k<NEST, false>(scene, 0);
@@ -1836,7 +1842,8 @@ hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, co
         if (e != hipSuccess) return e;
     }
     if (tile_scratch) {
-        const dim3 cgrid(blocks_for(rows.n_tiles));
+        const unsigned tiles_x = (camera.hsize + 7) / 8, tiles_y = (rows.n_tiles + tiles_x - 1) / tiles_x;
+        const dim3 cgrid(blocks_for(((tiles_x + 7) / 8) * ((tiles_y + 7) / 8) * 64u));  // one wave per 8x8 block of tiles
         if (scene.max_nesting == 0) classify_tiles_kernel<0><<<cgrid, 256, lds_bytes<0, false>(256), stream>>>(scene, camera, rows, tile_scratch);
         else classify_tiles_kernel<1><<<cgrid, 256, lds_bytes<1, false>(256), stream>>>(scene, camera, rows, tile_scratch);
         const dim3 ogrid((rows.n_tiles + ORDER_BLOCK - 1) / ORDER_BLOCK);
