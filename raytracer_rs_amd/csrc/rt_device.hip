@@ -31,10 +31,10 @@
 #ifdef RT_TIMING
 // Developer build (-DRT_TIMING): per-wave shader-clock totals of the phases of radiance() (tools/timing.py reads them).
 #define RT_TIMING_WAVES (1 << 20)
-__device__ unsigned long long g_rt_timing[RT_TIMING_WAVES][6];  // per wave: trace | shade<<32, real-time begin, iterations | lanes<<32, lifetime | real-time lifetime<<40, skip | group<<32 node visits, leaf visits | records fetched twice<<32
+__device__ unsigned long long g_rt_timing[RT_TIMING_WAVES][8];  // per wave: trace | shade<<32, real-time begin, iterations | lanes<<32, lifetime | real-time lifetime<<40, skip | group<<32 node visits, leaf visits | records fetched twice<<32, the tile rendered, unused
 extern "C" int rt_debug_timing(unsigned long long *out, unsigned n_waves) {
     if (n_waves > RT_TIMING_WAVES) n_waves = RT_TIMING_WAVES;
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rt_timing), (size_t)n_waves * 6 * sizeof(unsigned long long));
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rt_timing), (size_t)n_waves * 8 * sizeof(unsigned long long));
     return e == hipSuccess ? 0 : -4;
 }
 #define RT_TIC(var) const long long var = clock64()
@@ -1342,6 +1342,9 @@ __device__ __forceinline__ unsigned surface_weight(const SceneK &S, bool valid, 
     return (s->transparency > 0.0 || s->reflectivity > 0.0) ? 6u : 2u;
 }
 
+#ifndef RT_CLASSIFY_BOUNCES
+#define RT_CLASSIFY_BOUNCES 1
+#endif
 // One lane per tile: the cost estimate of the tile from its centre ray.
 template <int NEST>
 __global__ __launch_bounds__(256) void classify_tiles_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows,
@@ -1390,9 +1393,24 @@ __global__ __launch_bounds__(256) void classify_tiles_kernel(DeviceScene scene, 
             if (refracts) refracted = normal * (n_ratio * cos_i - sqrt(1.0 - sin2_t)) - eye * n_ratio;
         }
     }
-    if (__ballot(reflects) != 0ull) {
-        const Closest<false> child = trace<NEST, false, false>(S, over, reflected, reflects, (double)INFINITY, ctr);
-        if (reflects) weight += surface_weight(S, true, child);
+    // The reflection is followed for RT_CLASSIFY_BOUNCES more hits: a floor tile whose mirror image is a cluster of
+    // mirror balls has rays that go on bouncing among them, and is as slow as the cluster's own tiles.
+    V3 from = over, along = reflected;
+    bool bounces = reflects;
+    for (int bounce = 0; bounce <= RT_CLASSIFY_BOUNCES && __ballot(bounces) != 0ull; ++bounce) {
+        const Closest<false> child = trace<NEST, false, false>(S, from, along, bounces, (double)INFINITY, ctr);
+        if (bounces) weight += surface_weight(S, true, child);
+        bounces = bounces && child.leaf >= 0;
+        if (bounces) {
+            const RtSurface *c = S.surfaces + child.leaf;
+            const V3 point = from + along * child.t;
+            V3 object_point;
+            V3 normal = normal_at(c, point, object_point);
+            if (dot(normal, -along) < 0.0) normal = -normal;
+            from = point + normal * EPS;
+            along = reflect(along, normal);
+            bounces = c->reflectivity != 0.0;
+        }
     }
     if (__ballot(refracts) != 0ull) {
         const Closest<false> child = trace<NEST, false, false>(S, under, refracted, refracts, (double)INFINITY, ctr);
@@ -1490,6 +1508,9 @@ __global__ __launch_bounds__(RENDER_BLOCK, NEST > 0 ? RT_NEST_WAVES : 4) void re
     }
     V3 acc;
     radiance<NEST, STATS, TIES>(S, valid, ro, rd, max_depth, acc, ctr);
+#ifdef RT_TIMING
+    if (lane == 0 && blockIdx.x < RT_TIMING_WAVES) g_rt_timing[blockIdx.x][6] = tile;
+#endif
     // Canvas::write_pixel (rendering/canvas.rs:26-32) for the tile.  A lane's pixel is 3 values in the middle of a
     // row, so lanes storing their own pixels write 24-byte (or 3-byte) pieces 24 (3) bytes apart.  A whole tile is
     // instead laid out in LDS as its 8 rows of 24 values (the pending-ray stack is empty by now and lends the space)

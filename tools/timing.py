@@ -33,7 +33,7 @@ def main():
         bands = tuple(int(v) for v in os.environ["RT_TIMING_BANDS"].split(","))
         rows_rendered = sum(min(bands[0], h - y) for y in range(bands[1] * bands[0], h, bands[0] * bands[2]))
     n_waves = ((w + 7) // 8) * ((rows_rendered + 7) // 8)
-    buf = np.zeros((n_waves, 6), dtype=np.uint64)
+    buf = np.zeros((n_waves, 8), dtype=np.uint64)
     # one launch per frame, into device memory (rt_render cuts a frame into groups of rows, each a launch of its own
     # whose waves would overwrite each other's records)
     hip = ctypes.CDLL("libamdhip64.so")
@@ -91,12 +91,19 @@ def main():
     print("the tail (last waves to end): start us / lifetime us / rounds / start rank in the launch")
     rank = np.empty(len(order), dtype=np.int64)
     rank[order] = np.arange(len(order))
+    tiles_x = (w + 7) // 8
+    tile_of = buf[:, 6].astype(np.int64)
     for k in tail:
-        print(f"   {(rbegin[k] - t0) / 100:7.0f} {rlife[k] / 100:7.0f} {iters[k]:4.0f} {rank[k]:8d}")
+        print(f"   {(rbegin[k] - t0) / 100:7.0f} {rlife[k] / 100:7.0f} {iters[k]:4.0f} {rank[k]:8d}   tile x {tile_of[k] % tiles_x:4d} y {tile_of[k] // tiles_x:4d}")
+    # how well the launch order anticipates the cost: lifetimes by place in the order
+    by_rank = rlife[order] / 100
+    parts = np.array_split(by_rank, 16)
+    print("wave lifetime us by place in the launch order, sixteenths (mean / max):", " ".join(f"{p.mean():.0f}/{p.max():.0f}" for p in parts))
     started_late = np.nonzero((rend > p99) & (rbegin - t0 > 0.25 * (rend.max() - t0)))[0]
     print(f"waves ending after the 99th percentile: {len(np.nonzero(rend > p99)[0])}, of which started after the first quarter of the launch: {len(started_late)}")
-    tiles_x = (w + 7) // 8
-    rows = life.reshape(-1, tiles_x).mean(axis=1)
+    by_tile = np.zeros(n_waves)
+    by_tile[tile_of] = life
+    rows = by_tile.reshape(-1, tiles_x).mean(axis=1)
     step = max(1, len(rows) // 18)
     print("mean wave lifetime by tile row (top to bottom):", " ".join(f"{rows[i:i + step].mean() / 1000:.0f}k" for i in range(0, len(rows), step)))
 
