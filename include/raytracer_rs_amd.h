@@ -186,7 +186,12 @@ int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_rend
 /* The same on device memory, asynchronously on opts->stream: `rgb_device` receives only the rows rendered, packed:
  * (row_end-row_begin)*hsize*3 doubles starting at row_begin, or with bands the selected bands one after another
  * (band_rows*hsize*3 doubles each, the frame's last band possibly shorter).  No host synchronisation unless
- * collect_stats is set. */
+ * collect_stats is set.
+ * A handle serves ONE render at a time (as `&World` is borrowed for the duration of Camera::render): the scratch in
+ * which a launch orders its tiles, the counters and the timing marks belong to the handle, which is `const` here only
+ * in the sense that the world it holds does not change.  Launches of one handle on one stream are ordered by the
+ * stream; launches that may overlap in time (two streams, two host threads) need a handle each -- rt_scene_create is
+ * cheap, the world is a few kilobytes to a few megabytes. */
 int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
                      double *rgb_device, rt_stats *stats);
 
