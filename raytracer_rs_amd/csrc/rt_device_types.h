@@ -18,7 +18,14 @@
 
 // RtNode.xform: structure of `inv`, found on the host by exact comparison.  The traversal skips the products with
 // exact zeros (and with exact ones for the identity); that changes no value, only possibly the sign of a zero.
-enum { RT_XFORM_GENERAL = 0, RT_XFORM_DIAGONAL = 1 /* scale + translation */, RT_XFORM_IDENTITY = 2 };
+enum { RT_XFORM_GENERAL = 0, RT_XFORM_DIAGONAL = 1 /* scale + translation */, RT_XFORM_IDENTITY = 2,
+       RT_XFORM_DIAGONAL_BALL = 3 /* a sphere with a scale-and-translate transformation: see below */ };
+// RT_XFORM_DIAGONAL_BALL: of a scale-and-translate inverse the device reads inv[0], [3], [5], [7], [10], [11] only (the
+// other entries of the 3x3 part are exact zeros).  For a sphere, four of the unread entries hold a ball, in the space
+// of the sibling list the sphere stands in, that contains every point at which the reference can report a hit:
+//   inv[1], inv[2], inv[4]   its centre (the image of the sphere's origin)
+//   inv[6]                   its radius squared: the largest scale factor squared, padded, over 1 - 1e-9 (rt_flatten.cpp)
+// A wave none of whose rays comes near the ball skips the ray transform and the quadratic altogether.
 
 struct RtNode {
     double inv[12];   // rows 0..2 of inverse(transformation), row-major 3x4

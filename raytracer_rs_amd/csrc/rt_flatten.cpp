@@ -36,6 +36,35 @@ int32_t classify(const double m[12]) {
     return RT_XFORM_DIAGONAL;
 }
 
+// The ball of an RT_XFORM_DIAGONAL_BALL record (rt_device_types.h), from the inverse k_i x + t_i of a scale-and-translate
+// transformation: centre -t_i / k_i, radius max 1/|k_i|.  Returns false when no ball should be used.
+//
+// What the ball has to contain.  The reference reports a hit of the sphere when the discriminant it computes in the
+// sphere's own space from the transformed ray is not negative (geometry/sphere.rs:51-74).  Both the transformed ray
+// and the discriminant carry rounding errors, so a ray that truly passes the unit sphere at distance sqrt(1 + e) may
+// still be reported as hitting it: with L the distance of the transformed origin from the sphere's centre, in radii,
+// the transformed origin is off by at most 2^-52 (|o| + |centre|) |k| and the discriminant, relative to 4a, by a few
+// 2^-53 L^2.  With the scale factors at most a hundredfold apart (anything else gets no ball) both stay below
+// 1e-10 |o - centre|^2 + 1e-12 |centre|^2 in units of the list's space, with a factor of three to spare; the device
+// takes the first term off the squared distance it measures, the second is part of the radius here, and the 1e-9 on the
+// radius covers the rounding of the centre and of the device's own arithmetic.
+bool ball_of(const double inv[12], double centre[3], double &radius2) {
+    const double k[3] = {inv[0], inv[5], inv[10]}, t[3] = {inv[3], inv[7], inv[11]};
+    double smax = 0.0, smin = INFINITY, c2 = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        const double s = 1.0 / std::fabs(k[i]);
+        if (!(s > 0.0) || !std::isfinite(s)) return false;
+        smax = std::max(smax, s);
+        smin = std::min(smin, s);
+        centre[i] = -t[i] / k[i];
+        if (!std::isfinite(centre[i])) return false;
+        c2 += centre[i] * centre[i];
+    }
+    if (smax > 100.0 * smin) return false;
+    radius2 = (smax * smax * (1.0 + 1e-9) + 1e-12 * c2) / (1.0 - 1e-9);  // the device compares with |o - centre|^2 unshrunk
+    return std::isfinite(radius2);
+}
+
 // Shape::bounds of the leaf kinds
 Bounds leaf_bounds(const rt_object_desc &o) {
     switch (o.kind) {
@@ -453,6 +482,12 @@ struct Builder {
             n.xform = classify(n.inv);
             n.tag = o.kind | (o.closed ? RT_NODE_CLOSED : 0) | (int32_t)(depth << RT_NODE_LEVEL_SHIFT);
             n.leaf = -1;
+            double centre[3], radius2;
+            if (o.kind == RT_SPHERE && n.xform != RT_XFORM_GENERAL && ball_of(n.inv, centre, radius2)) {
+                n.xform = RT_XFORM_DIAGONAL_BALL;
+                n.inv[1] = centre[0]; n.inv[2] = centre[1]; n.inv[4] = centre[2];
+                n.inv[6] = radius2;
+            }
         }
 
         if (o.kind == RT_GROUP) {

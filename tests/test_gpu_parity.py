@@ -529,6 +529,67 @@ def test_range_skipping_on_rays_the_reference_treats_specially(gpu, rt, orc):
     _lone_rays_agree(orc, scene, oworld, rays)
 
 
+def test_sphere_balls_never_lose_a_hit(gpu, rt, orc):
+    """In a world without groups a wave skips a sphere when none of its rays comes near the ball the host put round
+    it.  The ball has to contain every point at which the reference can report a hit, rounding of its transformed ray
+    and of its discriminant included.  Rays that pass a sphere's silhouette at 1 +- 1e-15 .. 1e-6 radii (built in the
+    sphere's own space, so that the distance is what it says), from origins 1.5 to a million radii away, with
+    directions of several lengths; rays that start on or a hair outside the surface and head away (the reference's
+    larger root then is a difference of nearly equal numbers and may come out as 0 = a hit).  Spheres: at the origin;
+    a thousand and a hundred thousand units from it; stretched 4:1 and 300:1 (the latter gets no ball); of radius
+    0.022.  Each ray 64 times, so that its wave's decision is its own; the colour (materials are ambient only, one
+    colour per sphere) must be the oracle's: a lost hit is black instead of a colour."""
+    import tomli
+
+    spheres = [((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)), ((1000.5, -3.0, 7.0), (0.5, 0.5, 0.5)), ((5.0, 1.0, 0.0), (2.0, 0.5, 1.0)),
+               ((40.0, 0.0, 0.0), (0.022, 0.022, 0.022)), ((0.0, 30.0, 0.0), (300.0, 1.0, 1.0)), ((1.0e5, 0.0, 0.0), (1.0, 1.0, 1.0))]
+    lines = ["[camera]", "width = 64", "height = 48", "fov = 60.0", "from = [0.0, 2.0, -30.0]", "to = [0.0, 0.0, 0.0]",
+             "up = [0.0, 1.0, 0.0]", "[light]", "position = [-10.0, 500.0, -10.0]", "intensity = [1.0, 1.0, 1.0]"]
+    for k, (t, s) in enumerate(spheres):
+        lines += ["[[objects]]", 'type = "sphere"', "[objects.transform]", f"translate = [{t[0]}, {t[1]}, {t[2]}]",
+                  f"scale = [{s[0]}, {s[1]}, {s[2]}]", "[objects.material]", f"color = [{0.125 * (k + 1)}, 0.5, {1.0 - 0.125 * k}]",
+                  "ambient = 1.0", "diffuse = 0.0", "specular = 0.0"]
+    text = "\n".join(lines) + "\n"
+    sf = rt.SceneFile.from_str(text)
+    _, oworld = orc.scene_from_dict(tomli.loads(text))
+    scene = sf.build_world().scene()
+    assert scene.info().n_groups == 0
+
+    rng = np.random.default_rng(11)
+    rays = []
+    for t, s in spheres:
+        t, s = np.array(t), np.array(s)
+        for dist in (1.5, 30.0, 1.0e3, 1.0e6):
+            for off in (-1e-6, -1e-9, -1e-12, -1e-15, 0.0, 1e-15, 1e-12, 1e-9, 1e-6):
+                for _ in range(3):
+                    u = rng.normal(size=3)
+                    u /= np.linalg.norm(u)
+                    v = np.cross(u, rng.normal(size=3))
+                    v /= np.linalg.norm(v)
+                    o = (1.0 + off) * v - dist * u  # passes the unit sphere at distance 1 + off, in the sphere's space
+                    d = u * rng.choice([1.0, 1.0, 10.0, 0.1])
+                    rays.append([*(o * s + t), *(d * s)])
+        for off in (0.0, 1e-16, 1e-12, 1e-9, 1e-5, -1e-12):
+            for _ in range(6):
+                n = rng.normal(size=3)
+                n /= np.linalg.norm(n)
+                tangent = np.cross(n, rng.normal(size=3))
+                tangent /= np.linalg.norm(tangent)
+                for d in (n, n + 1e-3 * tangent, tangent + 1e-9 * n, tangent):
+                    rays.append([*((1.0 + off) * n * s + t), *(d * s)])
+    rays = np.array(rays, dtype=np.float64)
+    want = np.array([oworld.color_at(orc.ray(r[:3], r[3:])) for r in rays])
+    hit = (want != 0.0).any(axis=1)
+    assert 0.2 * len(rays) < hit.sum() < 0.8 * len(rays), hit.sum()
+    got = scene.color_at(np.repeat(rays, 64, axis=0)).reshape(len(rays), 64, 3)
+    # (a few rays that graze the 300:1 sphere give NaN in the reference's own arithmetic: NaN must then be the answer)
+    same = ((got == got[:, :1]) | (np.isnan(got) & np.isnan(got[:, :1]))).all(axis=(1, 2))
+    assert same.all(), (np.nonzero(~same)[0][:8], rays[~same][:4])
+    diff = np.where(np.isnan(want) & np.isnan(got[:, 0]), 0.0, np.abs(got[:, 0] - want))
+    wrong = np.nonzero(~(diff.max(axis=1) <= 1e-12))[0]
+    assert len(wrong) == 0, (len(wrong), rays[wrong[:5]], got[wrong[:5], 0], want[wrong[:5]])
+
+
 def test_cone_linear_shortcut_survives_range_skipping(gpu, rt, orc):
     """A ray with dx^2 - dy^2 + dz^2 below EPSILON in a cone's space: the reference takes t = -c / (2 b)
     (cones.rs:66-78), a point well off the cone and outside its bounding box, and accepts it because its y lies
@@ -955,6 +1016,22 @@ def test_full_4k_frame(gpu, rt, orc):
     for r in range(8):
         scene.render(cam, bands=(16, r, 8), out=acc)
     assert np.array_equal(acc, img)
+
+
+def test_full_hd_world_with_shadows(gpu, rt, orc):
+    """chapter_7_and_8 (six spheres, point light, shadow rays) at 1920x1080, the size the benchmark configuration
+    names: whole frame against the oracle, every counter, and exactly two rays per pixel only where geometry is hit."""
+    cam, world, ocam, oworld = load_both(rt, orc, "chapter_7_and_8", 1920, 1080)
+    scene = world.scene()
+    img, st = scene.render(cam, stats=True)
+    oc = orc.Counters()
+    ref = orc.render(ocam, oworld, threads=16, counters=oc)
+    assert_frames_match(orc, img, ref)
+    counters_equal(st, oc)
+    assert st.primary == 1920 * 1080 and st.reflect == 0 and st.refract == 0
+    assert st.rays == st.primary + st.shadow and st.shadow == st.shades <= st.primary
+    plain, _ = scene.render(cam)
+    assert np.array_equal(plain, img)
 
 
 def _full_size_checks(orc, scene, cam, ocam, oworld, n_sample_bands, band_rows=4):
