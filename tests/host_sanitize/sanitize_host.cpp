@@ -115,6 +115,18 @@ void feed(const std::string &text, Tally &tally) {
                 if (kind < RT_SPHERE || kind > RT_CONE) fail("unknown kind", t * per_table + i);
                 if (n.leaf < 0 || (size_t)n.skip != i + 1) fail("leaf without a surface or with a range", t * per_table + i);
                 seen[(size_t)n.leaf]++;
+                if (n.xform == RT_XFORM_DIAGONAL_BALL) {
+                    // the four entries that hold the ball are entries the device never reads as a matrix for this
+                    // class; the ball is centred on the image of the sphere's origin and holds the whole sphere
+                    if (kind != RT_SPHERE) fail("a ball on something that is not a sphere", t * per_table + i);
+                    if (n.inv[8] != 0.0 || n.inv[9] != 0.0) fail("a ball on a matrix that is not scale-and-translate", t * per_table + i);
+                    const double k[3] = {n.inv[0], n.inv[5], n.inv[10]}, tr[3] = {n.inv[3], n.inv[7], n.inv[11]}, c[3] = {n.inv[1], n.inv[2], n.inv[4]};
+                    for (int a = 0; a < 3; ++a) {
+                        if (!(std::fabs(c[a] * k[a] + tr[a]) <= 1e-12 * (std::fabs(tr[a]) + 1.0))) fail("ball not centred on the sphere", t * per_table + i);
+                        if (!(n.inv[6] * k[a] * k[a] > 1.0)) fail("ball smaller than its sphere", t * per_table + i);
+                    }
+                    if (!std::isfinite(n.inv[6])) fail("ball without a radius", t * per_table + i);
+                }
             }
         }
         for (size_t l = 0; l < seen.size(); ++l)
