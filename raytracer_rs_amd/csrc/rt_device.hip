@@ -312,6 +312,14 @@ __device__ __forceinline__ bool hit_plane(V3 o, V3 d, bool on, int leaf, B &best
     return true;
 }
 
+// Is Plane::local_intersect's t = -o.y / d.y certainly not a hit (negative and not zero)?  The sign of a correctly
+// rounded quotient is the sign of the exact one unless it underflows to zero (-0.0 >= 0.0 holds, so a zero counts as a
+// hit): o.y and d.y of the same sign, and |o.y / d.y| >= 2^-500.  (A ray with |d.y| < EPSILON is no hit either, but
+// that the plane's own test finds out quickly enough.)
+__device__ __forceinline__ bool plane_behind(double oy, double dy) {
+    return (oy * dy > 0.0) & (fabs(oy) >= fabs(dy) * 0x1p-500);
+}
+
 // geometry/cubes.rs:63-86.  Both roots are emitted only when !(tmin > tmax).
 template <class B>
 __device__ __forceinline__ bool hit_cube(V3 o, V3 d, bool on, int leaf, B &best) {
@@ -597,7 +605,13 @@ __device__ __forceinline__ void trace_flat(const SceneK &S, V3 o, V3 d, bool act
         const int kind = w.tag & 0xff;
         bool visit = true;  // wave-uniform
         if constexpr (!STATS && !B::every) {  // (the counting kernel tests what the reference tests)
-            if (xform == RT_XFORM_DIAGONAL_BALL) visit = __ballot(active & !misses_ball(raw, o, d, dd)) != 0ull;
+            if (xform == RT_XFORM_DIAGONAL_BALL) {
+                visit = __ballot(active & !misses_ball(raw, o, d, dd)) != 0ull;
+            } else if (kind == RT_PLANE && xform != RT_XFORM_GENERAL) {
+                // the y components of the ray in the plane's space, as to_local computes them
+                const double ky = dwords_to_double(raw.a[10], raw.a[11]);
+                visit = __ballot(active & !plane_behind(ky * o.y + dwords_to_double(raw.a[14], raw.a[15]), ky * d.y)) != 0ull;
+            }
         }
         NodeRaw nraw;
         RT_NODE_VISIT(2);

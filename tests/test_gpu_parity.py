@@ -577,17 +577,46 @@ def test_sphere_balls_never_lose_a_hit(gpu, rt, orc):
                 tangent /= np.linalg.norm(tangent)
                 for d in (n, n + 1e-3 * tangent, tangent + 1e-9 * n, tangent):
                     rays.append([*((1.0 + off) * n * s + t), *(d * s)])
-    rays = np.array(rays, dtype=np.float64)
+    hits = _lone_colours_agree(orc, scene, oworld, np.array(rays, dtype=np.float64))
+    assert 0.2 * len(rays) < hits < 0.8 * len(rays), hits
+
+
+def _lone_colours_agree(orc, scene, oworld, rays):
+    """World::color_at of every ray alone in its wave (64 copies of it) against the oracle's; returns how many of the
+    rays see anything.  Where the reference's own arithmetic gives NaN, NaN must be the answer."""
     want = np.array([oworld.color_at(orc.ray(r[:3], r[3:])) for r in rays])
-    hit = (want != 0.0).any(axis=1)
-    assert 0.2 * len(rays) < hit.sum() < 0.8 * len(rays), hit.sum()
     got = scene.color_at(np.repeat(rays, 64, axis=0)).reshape(len(rays), 64, 3)
-    # (a few rays that graze the 300:1 sphere give NaN in the reference's own arithmetic: NaN must then be the answer)
     same = ((got == got[:, :1]) | (np.isnan(got) & np.isnan(got[:, :1]))).all(axis=(1, 2))
     assert same.all(), (np.nonzero(~same)[0][:8], rays[~same][:4])
     diff = np.where(np.isnan(want) & np.isnan(got[:, 0]), 0.0, np.abs(got[:, 0] - want))
     wrong = np.nonzero(~(diff.max(axis=1) <= 1e-12))[0]
     assert len(wrong) == 0, (len(wrong), rays[wrong[:5]], got[wrong[:5], 0], want[wrong[:5]])
+    return int((want != 0.0).any(axis=1).sum())
+
+
+def test_plane_skipping_keeps_the_hit_at_zero(gpu, rt, orc):
+    """A wave skips a plane when every ray heads away from it (t = -o.y / d.y negative).  Negative, not zero: a
+    quotient that underflows is -0.0, and -0.0 >= 0.0 makes it a hit in the reference (intersections.rs:37-39).
+    Origins a denormal above the plane with steep directions, origins exactly on it (+0.0 and -0.0), ordinary rays
+    towards and away from it, rays nearly parallel to it; a scaled and translated plane, so that its own space
+    differs from the world's."""
+    import tomli
+
+    lines = ["[camera]", "width = 64", "height = 48", "fov = 60.0", "from = [0.0, 2.0, -30.0]", "to = [0.0, 0.0, 0.0]",
+             "up = [0.0, 1.0, 0.0]", "[light]", "position = [-10.0, 500.0, -10.0]", "intensity = [1.0, 1.0, 1.0]",
+             "[[objects]]", 'type = "plane"', "[objects.material]", "color = [0.25, 0.5, 0.75]", "ambient = 1.0", "diffuse = 0.0", "specular = 0.0",
+             "[[objects]]", 'type = "plane"', "[objects.transform]", "translate = [0.0, -4.0, 0.0]", "scale = [2.0, 0.5, 3.0]",
+             "[objects.material]", "color = [0.75, 0.25, 0.5]", "ambient = 1.0", "diffuse = 0.0", "specular = 0.0"]
+    text = "\n".join(lines) + "\n"
+    sf = rt.SceneFile.from_str(text)
+    _, oworld = orc.scene_from_dict(tomli.loads(text))
+    scene = sf.build_world().scene()
+    rays = []
+    for oy in (5e-324, 1e-320, 1e-310, 1e-300, 1e-200, 1e-20, 0.0, -0.0, 1.0, -5e-324, -1e-300, -1.0, 3.0, -4.0, -4.0 + 1e-15, -5.0):
+        for dy in (1.0, -1.0, 1e5, -1e5, 1e150, -1e150, 1e300, -1e300, 2e-5, -2e-5, 0.9e-5, 1e-300, 0.0):
+            rays.append([0.5, oy, -0.25, 0.1, dy, 0.2])
+    hits = _lone_colours_agree(orc, scene, oworld, np.array(rays, dtype=np.float64))
+    assert 0.3 * len(rays) < hits < 0.95 * len(rays), hits
 
 
 def test_cone_linear_shortcut_survives_range_skipping(gpu, rt, orc):
