@@ -1063,7 +1063,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
     const V3 light_pos = mk(S.light.position[0], S.light.position[1], S.light.position[2]);
 
 #ifdef RT_TIMING
-    long long tm_trace = 0, tm_shade = 0, tm_iters = 0, tm_lanes = 0;
+    long long tm_trace = 0, tm_shade = 0, tm_iters = 0, tm_lanes = 0, tm_hist = 0;
     const long long tm_begin = clock64();
     const long long tm_rbegin = wall_clock64();
     if (threadIdx.x < 4) rt_wave_nodes[threadIdx.x] = 0;
@@ -1295,6 +1295,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
             tm_shade += (tm2 - tm1) + (tm4 - tm3);
             tm_iters += 1;
             tm_lanes += __popcll(__ballot(have));
+            { const int n_ = __popcll(__ballot(have)); tm_hist += (n_ <= 8 ? 1ll : 0ll) + (n_ <= 16 ? (1ll << 16) : 0ll) + (n_ <= 32 ? (1ll << 32) : 0ll) + (n_ <= 48 ? (1ll << 48) : 0ll); }
         }
 #endif
     }
@@ -1308,6 +1309,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
             g_rt_timing[wv][3] = (unsigned long long)(clock64() - tm_begin) | ((unsigned long long)(wall_clock64() - tm_rbegin) << 40);
             g_rt_timing[wv][4] = (unsigned long long)rt_wave_nodes[0] | ((unsigned long long)rt_wave_nodes[1] << 32);
             g_rt_timing[wv][5] = (unsigned long long)rt_wave_nodes[2] | ((unsigned long long)rt_wave_nodes[3] << 32);
+            g_rt_timing[wv][7] = (unsigned long long)tm_hist;
         }
     }
 #endif

@@ -76,6 +76,10 @@ def main():
           f"active lanes/iteration {lanes.sum() / iters.sum():.1f}")
     print(f"per wave: lifetime {life.mean():.0f} clk (max {life.max():.0f}), trace {trace.mean():.0f} clk, shade {shade.mean():.0f} clk")
     print(f"per iteration: trace {trace.sum() / iters.sum():.0f} clk, shade {shade.sum() / iters.sum():.0f} clk")
+    hist = buf[:, 7]
+    le = [int(((hist >> np.uint64(16 * k)) & np.uint64(0xFFFF)).sum()) for k in range(4)]
+    print("rounds by lanes holding a ray afterwards: <= 8: %.1f %%, <= 16: %.1f %%, <= 32: %.1f %%, <= 48: %.1f %% of %d rounds"
+          % tuple([100.0 * v / iters.sum() for v in le] + [int(iters.sum())]))
     skipn, groupn, leafn = (buf[:, 4] & m32).astype(float), (buf[:, 4] >> np.uint64(32)).astype(float), (buf[:, 5] & m32).astype(float)
     again = (buf[:, 5] >> np.uint64(32)).astype(float)
     nodes = skipn + groupn + leafn
