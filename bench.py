@@ -406,11 +406,13 @@ def main() -> None:
                          "algorithmic_flops_per_launch": my_flops,
                          "note": "FP64 vector ALU is the bounding unit (no dense contraction, scene cache-resident); "
                                  "peak counts an FMA as 2 flops, the kernel is built without FMA contraction to keep "
-                                 "the reference's rounding, so its own ceiling is half of peak; algorithmic flops count "
-                                 "the reference's 33-flop ray transform per object although the kernel executes 9 for "
-                                 "scale-and-translate inverses (every sphere of chapter_11)"},
+                                 "the reference's rounding, so its own ceiling is half of peak; algorithmic flops are "
+                                 "the REFERENCE's work for the same rays (every ray against every object, 33 flops per "
+                                 "ray transform): the kernel executes 9 per scale-and-translate inverse and skips a "
+                                 "sphere or plane that no ray of a wave can hit (executed_flops is what it issued)"},
         }
-        line["roofline"].update(committed_traffic() if headline and u8 else {"traffic": None})
+        # the committed PMC figures are per launch of the WHOLE frame: they describe a one-GPU run only
+        line["roofline"].update(committed_traffic() if headline and u8 and world_size == 1 else {"traffic": None})
         if world_size == 1 and not multi:
             peak = measured_fp64_peak()
             if peak:
