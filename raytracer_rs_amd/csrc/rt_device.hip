@@ -984,8 +984,8 @@ __device__ __forceinline__ void ray_for_pixel(const RtCameraDev &cam, unsigned p
 // the path from the root.  That differs from the nested form only by floating-point reassociation (a few ulp).
 //
 // One round of the loop takes every lane's current radiance ray through: traversal; for the lanes that hit, shading
-// for both outcomes of the shadow test and the reflection and refraction rays (pushed on a per-lane stack, refraction
-// first, so that the reflection subtree is walked first); traversal of the shadow rays; choice between the two sums;
+// for both outcomes of the shadow test and the reflection and refraction rays (pushed on a per-lane stack: the one with
+// the shorter ray tree to expect last, so that it is walked first); traversal of the shadow rays; choice between the two sums;
 // next ray from the stack.  All lanes of a wave are thus always in the same phase: the two traversals never mix
 // scattered radiance rays with the coherent shadow rays, and the shading code runs once per round.  A lane whose
 // ray missed simply sits out the shadow traversal.
@@ -1085,7 +1085,8 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
             V3 object_point;
             V3 normal = normal_at(s, point, object_point);
             V3 eye = -rd;
-            if (dot(normal, eye) < 0.0) normal = -normal;
+            const bool from_inside = dot(normal, eye) < 0.0;
+            if (from_inside) normal = -normal;
             V3 over = point + normal * EPS;
             ctr.add(C_SHADES);
 
@@ -1148,15 +1149,22 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
                 w_refract = w_refract * (1.0 - reflectance);
             }
             const int child_remaining = remaining - 1;
-            // The child pushed last is walked first: reflection before refraction, whatever side of the surface the
-            // ray is on.  (Walking the refraction first for hits from inside an object -- it leaves, the reflection
-            // stays inside and has the longer ray tree -- keeps the stack shorter: 63 % fewer bytes spilled to
-            // scratch, measured, but 2 % more time per frame.)
+            // The child pushed last is walked first.  For a hit from outside that is the reflection; for a hit from
+            // INSIDE an object the refraction: it leaves the object and its ray tree is short, while the reflection
+            // stays inside and goes on spawning exit rays, one pending per bounce.  Walking the short tree first
+            // keeps the stack of pending rays shallow: on the 4K chapter_11 frame the bytes that pending rays below
+            // the LDS levels write to scratch memory fall from 0.61 GB to 0.21 GB per frame, and the frame is 1 %
+            // faster.  The order in which a pixel's terms are summed changes with it, the terms do not.
+            const bool reflect_last = do_reflect && !from_inside;
+            if (do_reflect && !reflect_last) {  // over_point, reflect_vector (intersections.rs:60-62)
+                ctr.add(C_REFLECT);
+                push(over, reflect(rd, normal), w_reflect, child_remaining);
+            }
             if (do_refract) {  // under_point, direction (intersections.rs:63, world.rs:194)
                 ctr.add(C_REFRACT);
                 push(point - normal * EPS, refr_dir, w_refract, child_remaining);
             }
-            if (do_reflect) {  // over_point, reflect_vector (intersections.rs:60-62)
+            if (reflect_last) {
                 ctr.add(C_REFLECT);
                 push(over, reflect(rd, normal), w_reflect, child_remaining);
             }
