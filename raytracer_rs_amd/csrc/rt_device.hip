@@ -872,11 +872,24 @@ __device__ __forceinline__ V3 local_normal_at(int kind, double minimum, double m
 
 // Object::normal_at (rendering/objects.rs:171-184)
 // `object_point` = world_to_object(world_point) (objects.rs:87-91), which Pattern::color_at_object needs again.
+// DIAGONAL: leave out the products with the exact zeros of a scale-and-translate inverse, as the ray transform does
+// (at most the sign of a zero differs).  The choice is per lane; it pays where a wave's hits are mostly on such
+// objects -- the flat scenes of the book -- and costs where rotated and unrotated leaves mix.
+template <bool DIAGONAL = false>
 __device__ __forceinline__ V3 normal_at(const RtSurface *s, V3 world_point, V3 &object_point) {
-    V3 lp = mul_point(s->inv_world, world_point);
-    object_point = lp;
-    V3 ln = local_normal_at(s->kind, s->minimum, s->maximum, lp);
-    V3 wn = mul_vector_transposed(s->inv_world, ln);
+    const double *m = s->inv_world;
+    V3 lp, wn;
+    if (DIAGONAL && s->xform != RT_XFORM_GENERAL) {
+        lp = mk(m[0] * world_point.x + m[3], m[5] * world_point.y + m[7], m[10] * world_point.z + m[11]);
+        object_point = lp;
+        V3 ln = local_normal_at(s->kind, s->minimum, s->maximum, lp);
+        wn = mk(m[0] * ln.x, m[5] * ln.y, m[10] * ln.z);
+    } else {
+        lp = mul_point(m, world_point);
+        object_point = lp;
+        V3 ln = local_normal_at(s->kind, s->minimum, s->maximum, lp);
+        wn = mul_vector_transposed(m, ln);
+    }
     return div_by_magnitude(wn, magnitude(wn));
 }
 
@@ -1083,7 +1096,7 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
             const RtSurface *s = S.surfaces + best.leaf;
             V3 point = ro + rd * best.t;
             V3 object_point;
-            V3 normal = normal_at(s, point, object_point);
+            V3 normal = normal_at<NEST == 0>(s, point, object_point);
             V3 eye = -rd;
             const bool from_inside = dot(normal, eye) < 0.0;
             if (from_inside) normal = -normal;

@@ -66,7 +66,7 @@ struct RtSurface {
     int32_t kind;
     int32_t pattern_kind;  // RT_PATTERN_*
     int32_t object;
-    int32_t _pad;
+    int32_t xform;         // RT_XFORM_* of inv_world (never RT_XFORM_DIAGONAL_BALL)
 };
 
 struct RtLight {

@@ -507,6 +507,7 @@ struct Builder {
         RtSurface s;
         std::memset(&s, 0, sizeof s);
         rows3(*Winv, s.inv_world);
+        s.xform = classify(s.inv_world);
         const rt_material_desc &m = o.material;
         for (int i = 0; i < 3; ++i) s.color[i] = m.color[i];
         s.ambient = m.ambient; s.diffuse = m.diffuse; s.specular = m.specular; s.shininess = m.shininess;
