@@ -42,12 +42,16 @@ int32_t classify(const double m[12]) {
 // What the ball has to contain.  The reference reports a hit of the sphere when the discriminant it computes in the
 // sphere's own space from the transformed ray is not negative (geometry/sphere.rs:51-74).  Both the transformed ray
 // and the discriminant carry rounding errors, so a ray that truly passes the unit sphere at distance sqrt(1 + e) may
-// still be reported as hitting it: with L the distance of the transformed origin from the sphere's centre, in radii,
-// the transformed origin is off by at most 2^-52 (|o| + |centre|) |k| and the discriminant, relative to 4a, by a few
-// 2^-53 L^2.  With the scale factors at most a hundredfold apart (anything else gets no ball) both stay below
-// 1e-10 |o - centre|^2 + 1e-12 |centre|^2 in units of the list's space, with a factor of three to spare; the device
-// takes the first term off the squared distance it measures, the second is part of the radius here, and the 1e-9 on the
-// radius covers the rounding of the centre and of the device's own arithmetic.
+// still be reported as hitting it.  In the sphere's space, with L the distance of the transformed origin from the
+// centre: the transformed origin k_i o_i + t_i is off by at most 2^-52 |k| (|o| + |centre|), which moves the squared
+// distance of the line by at most 2 L times that; and b^2 - 4ac, in units of 4a, is off by at most some thirty
+// 2^-53 L^2.  Back in the list's space (distances scale by at most the largest scale factor, L <= |o - centre| over
+// the smallest, |k| <= 1 over the smallest) and with the scale factors at most a hundredfold apart -- anything else
+// gets no ball -- that is an excess of the squared distance of at most
+//     4.2e-11 |o - centre|^2 + 4.4e-12 |centre|^2.
+// The device takes 1e-9 |o - centre|^2 off the squared distance it measures and the radius here carries 1e-10
+// |centre|^2: more than twenty times the bound each.  The 1e-9 on the radius itself covers the rounding of the
+// centre and of the device's own arithmetic.
 bool ball_of(const double inv[12], double centre[3], double &radius2) {
     const double k[3] = {inv[0], inv[5], inv[10]}, t[3] = {inv[3], inv[7], inv[11]};
     double smax = 0.0, smin = INFINITY, c2 = 0.0;
@@ -61,7 +65,7 @@ bool ball_of(const double inv[12], double centre[3], double &radius2) {
         c2 += centre[i] * centre[i];
     }
     if (smax > 100.0 * smin) return false;
-    radius2 = (smax * smax * (1.0 + 1e-9) + 1e-12 * c2) / (1.0 - 1e-9);  // the device compares with |o - centre|^2 unshrunk
+    radius2 = (smax * smax * (1.0 + 1e-9) + 1e-10 * c2) / (1.0 - 1e-9);  // the device compares with |o - centre|^2 unshrunk
     return std::isfinite(radius2);
 }
 
