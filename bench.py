@@ -123,7 +123,7 @@ def committed_traffic() -> dict:
 
 def kernel_name(scene) -> str:
     info = scene.info()
-    return "render_kernel<false, 1, true>" if (info.n_groups > 0 or info.n_objects > 12) else "render_kernel<false, 0, false>"
+    return {0: "render_kernel<false, 0, false>", 2: "render_kernel<false, 2, true>"}.get(info.kernel_build, "render_kernel<false, 1, true>")
 
 
 def time_config(scene, cam, stream, reps: int, quantized: bool) -> dict:

@@ -140,7 +140,7 @@ pub struct rt_scene_info {
     pub max_nesting: u32,
     pub device_bytes: u64,
     pub device: i32,
-    pub _pad: i32,
+    pub kernel_build: i32,
 }
 
 #[repr(C)]

@@ -149,7 +149,8 @@ typedef struct rt_scene_info {
     uint32_t n_objects, n_leaves, n_groups, max_nesting;
     uint64_t device_bytes;
     int32_t device;
-    int32_t _pad;
+    int32_t kernel_build; /* which build of the render kernel serves this world: 0 = a table of leaves only (no groups, at
+                             most 12 objects), 1 = any table, 2 = a table in which no range of nodes holds a cone */
 } rt_scene_info;
 
 /* struct Computations (rendering/intersections.rs:12-24); `object` is an index into rt_world_desc.objects. */

@@ -95,7 +95,7 @@ class RenderOpts(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_objects", C.c_uint32), ("n_leaves", C.c_uint32), ("n_groups", C.c_uint32),
-                ("max_nesting", C.c_uint32), ("device_bytes", C.c_uint64), ("device", C.c_int32), ("_pad", C.c_int32)]
+                ("max_nesting", C.c_uint32), ("device_bytes", C.c_uint64), ("device", C.c_int32), ("kernel_build", C.c_int32)]
 
 
 # every symbol include/raytracer_rs_amd.h declares: name -> (restype, argtypes)

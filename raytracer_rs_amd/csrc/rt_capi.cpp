@@ -229,6 +229,9 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     sc->dev.max_nesting = (int32_t)sc->flat.max_nesting;
     if ((sc->flat.n_skip_nodes || sc->flat.n_groups) && sc->dev.max_nesting < 1) sc->dev.max_nesting = 1;
     sc->dev.any_order = sc->flat.reordered ? 1 : 0;
+    sc->dev.cone_nodes = 0;
+    for (const RtNode &n : sc->flat.nodes)
+        if ((n.tag & 0xff) == RT_SKIPBOX && n.xform == RT_SKIP_CONES) sc->dev.cone_nodes = 1;
     sc->dev.light = sc->flat.light;
     // In a flat scene without reflective or transparent surfaces every pixel costs one or two rays over the same
     // few objects: nothing to gain from launching the tiles in any particular order.
@@ -273,6 +276,7 @@ int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out) {
     out->max_nesting = scene->flat.max_nesting;
     out->device_bytes = scene->device_bytes;
     out->device = scene->device;
+    out->kernel_build = scene->dev.max_nesting == 0 ? 0 : (scene->dev.any_order != 0 && scene->dev.cone_nodes == 0) ? 2 : 1;
     return RT_OK;
 }
 

@@ -679,7 +679,9 @@ struct ParkedRays {
 // fetches the parked ray back.  `far`: hits beyond it do not matter to the caller (range-skip nodes use it; the t
 // parameter is the same in every space because directions are never renormalised).  Per node as in trace_flat: ray
 // into the node's space, next record requested over the current one, test while the request is in flight.
-template <bool STATS, class B>
+// CONES false: no range-skip node of the table has cones below it (a kernel built without the cone-direction code
+// keeps fewer values across the record loop).
+template <bool STATS, class B, bool CONES = true>
 __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool active0, double far, B &best, Ctr<STATS> &ctr) {
     const int end = S.n_nodes;
     if (end <= 0) return;
@@ -728,7 +730,7 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
         double qdd = 0.0;
         if (kind == RT_SKIPBOX) {
             if constexpr (!STATS && !B::every) {
-                if (xform == RT_SKIP_CONES) {
+                if (CONES && xform == RT_SKIP_CONES) {
                     double m[7];
 #pragma unroll
                     for (int k = 0; k < 7; ++k) m[k] = dwords_to_double(raw.a[2 * k], raw.a[2 * k + 1]);
@@ -768,7 +770,7 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
                         const double rb[6] = {(double)__int_as_float(raw.a[14]), (double)__int_as_float(raw.a[15]), (double)__int_as_float(raw.b[0]),
                                               (double)__int_as_float(raw.b[1]), (double)__int_as_float(raw.b[2]), (double)__int_as_float(raw.b[3])};
                         const double rbound = dwords_to_double(raw.b[4], raw.b[5]);
-                        const bool rshort = xform == RT_SKIP_CONES && !(fabs(qdd) >= rbound);
+                        const bool rshort = CONES && xform == RT_SKIP_CONES && !(fabs(qdd) >= rbound);
                         const bool rmay = active && !settled(best) && (rshort || box_may_hit(rb, co, inv_d, dmax, hit_limit(best, far)));
                         ctr.visits += rmay ? 1u : 0u;
                         guess = __ballot(rmay) != 0ull ? w.skip + 1 : w.leaf;
@@ -817,6 +819,10 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
     }
 }
 
+// NEST, the template parameter of the kernels: 0 = a table of leaves only; 1 = anything; 2 = a table with groups or
+// range-skip nodes none of which has cones below it (render_kernel only: the kernel then carries no cone-direction
+// code, and spills a quarter fewer registers in the record loop -- chapter_14 at 4K 5.34 -> 5.09 ms).
+constexpr bool nest_cones(int nest) { return nest != 2; }
 template <int NEST, bool STATS, bool TIES = ANY_ORDER<NEST>>
 __device__ __forceinline__ Closest<TIES> trace(const SceneK &S, V3 o, V3 d, bool active, double far, Ctr<STATS> &ctr) {
     Closest<TIES> best;
@@ -824,7 +830,7 @@ __device__ __forceinline__ Closest<TIES> trace(const SceneK &S, V3 o, V3 d, bool
     best.leaf = -1;
     if (STATS && active) ctr.add(C_RAYS);
     if constexpr (NEST == 0) trace_flat<STATS>(S, o, d, active, best, ctr);
-    else trace_nested<STATS>(S, o, d, active, far, best, ctr);
+    else trace_nested<STATS, Closest<TIES>, nest_cones(NEST)>(S, o, d, active, far, best, ctr);
     return best;
 }
 
@@ -836,7 +842,7 @@ __device__ __forceinline__ bool occluded(const SceneK &S, V3 o, V3 d, bool activ
     oc.t = __builtin_nan("");
     if (STATS && active) ctr.add(C_RAYS);
     if constexpr (NEST == 0) trace_flat<STATS>(S, o, d, active, oc, ctr);
-    else trace_nested<STATS>(S, o, d, active, distance, oc, ctr);
+    else trace_nested<STATS, Occluded, nest_cones(NEST)>(S, o, d, active, distance, oc, ctr);
     return oc.t < distance;
 }
 
@@ -1916,7 +1922,8 @@ static void launch_render_nest(int nest, dim3 grid, unsigned block, hipStream_t 
     }
     // The counting variant always breaks ties by leaf number (right for any table order, and its speed does not
     // matter); the plain one only when the host reordered a sibling list, because the comparison is paid per candidate.
-    if (STATS || scene.any_order != 0) RT_LAUNCH(1, true);
+    if (!STATS && scene.any_order != 0 && scene.cone_nodes == 0) RT_LAUNCH(2, true);
+    else if (STATS || scene.any_order != 0) RT_LAUNCH(1, true);
     else RT_LAUNCH(1, false);
 #undef RT_LAUNCH
 }
