@@ -706,6 +706,8 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
     V3 inv_d = mk(0.0, 0.0, 0.0);  // for range-skip nodes: 1/cd per axis, computed at the first one met after a change of level
     double dmax = 0.0;
     bool have_inv = false;
+    double list_qdd = 0.0;  // d^T q d for the list being walked, once a node that shares the list's q has formed it
+    bool have_q = false;
     int i = 0;
     while (i < end) {
         const NodeWords w = node_words(raw);
@@ -721,7 +723,7 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
                 parked.fetch(lvl, co, cd);
             }
             level = lvl;
-            have_inv = false;
+            have_inv = false, have_q = false;
         }
         const bool active = act == level;
         // Everything that reads the first 96 bytes of the record happens before the next record is requested.
@@ -734,8 +736,17 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
                     double m[7];
 #pragma unroll
                     for (int k = 0; k < 7; ++k) m[k] = dwords_to_double(raw.a[2 * k], raw.a[2 * k + 1]);
-                    qdd = (m[0] * cd.x + m[1] * cd.y + m[2] * cd.z) * cd.x + (m[1] * cd.x + m[3] * cd.y + m[4] * cd.z) * cd.y +
-                          (m[2] * cd.x + m[4] * cd.y + m[5] * cd.z) * cd.z;
+                    const bool list_q = (w.tag & RT_NODE_LIST_Q) != 0;  // every such node of this list has this very q
+                    if (list_q && have_q) {
+                        qdd = list_qdd;
+                    } else {
+                        qdd = (m[0] * cd.x + m[1] * cd.y + m[2] * cd.z) * cd.x + (m[1] * cd.x + m[3] * cd.y + m[4] * cd.z) * cd.y +
+                              (m[2] * cd.x + m[4] * cd.y + m[5] * cd.z) * cd.z;
+                        if (list_q) {
+                            list_qdd = qdd;
+                            have_q = true;
+                        }
+                    }
                     shortcut = !(fabs(qdd) >= m[6]);
                 }
             }
@@ -798,7 +809,7 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
                 cd = ld;
                 level = level + 1;
                 act = inside ? level : act;
-                have_inv = false;
+                have_inv = false, have_q = false;
                 ni = i + 1;
             }
         } else if (kind != RT_SKIPBOX) {

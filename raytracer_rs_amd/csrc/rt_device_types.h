@@ -41,6 +41,8 @@ struct RtNode {
 #define RT_NODE_LEVEL_SHIFT 9
 #define RT_NODE_LEVEL_MASK 0x7f
 #define RT_NODE_LOOKAHEAD 0x10000 /* range-skip node: also holds the box of the range-skip node at `skip` (below) */
+#define RT_NODE_LIST_Q 0x20000    /* RT_SKIP_CONES node whose q (inv[0..5]) is, bit for bit, that of every other such node of its
+                                     sibling list: d^T q d of a ray need be formed once per visit of the list */
 // A node kind of this table only (the reference has no such object): a conservative box, in the space of the
 // sibling list it stands in, around the nodes (i, skip).  When no ray of a wave can touch the box the traversal
 // continues at `skip`; otherwise at i + 1, with the same ray.  Its matrix is the identity and it has no leaf.

@@ -465,9 +465,27 @@ struct Builder {
     }
 
     bool emit_list(const ListLayout &L, uint32_t depth, unsigned oct) {
+        const size_t first = nodes->size();
         for (uint32_t m : L.unbounded)
             if (!emit(m, depth, oct)) return false;
-        return L.root < 0 || emit_tree(L, L.root, depth, oct, -1);
+        if (L.root >= 0 && !emit_tree(L, L.root, depth, oct, -1)) return false;
+        // The range-skip nodes of THIS list that have cones below them: when their q's agree (they do whenever the
+        // cones of the list differ by rotations about their axes, uniform scales and translations), all get the
+        // first one's, and the device forms d^T q d once per visit of the list instead of once per node.
+        std::vector<size_t> with_q;
+        for (size_t i = first; i < nodes->size(); ++i) {
+            const RtNode &n = (*nodes)[i];
+            if ((n.tag & 0xff) == RT_SKIPBOX && (uint32_t)((n.tag >> RT_NODE_LEVEL_SHIFT) & RT_NODE_LEVEL_MASK) == depth && n.xform == RT_SKIP_CONES) with_q.push_back(i);
+        }
+        bool agree = with_q.size() > 1;
+        for (size_t k = 1; k < with_q.size() && agree; ++k)
+            for (int c = 0; c < 6; ++c) agree = agree && std::fabs((*nodes)[with_q[k]].inv[c] - (*nodes)[with_q[0]].inv[c]) <= 1e-9;
+        if (agree)
+            for (size_t i : with_q) {
+                for (int c = 0; c < 6; ++c) (*nodes)[i].inv[c] = (*nodes)[with_q[0]].inv[c];
+                (*nodes)[i].tag |= RT_NODE_LIST_Q;
+            }
+        return true;
     }
 
     // Appends object `idx` and its subtree.

@@ -83,6 +83,7 @@ void feed(const std::string &text, Tally &tally) {
         const RtNode *tab = flat.nodes.data() + t * per_table;
         std::vector<unsigned> seen(flat.surfaces.size(), 0);
         std::vector<std::pair<size_t, int>> open;  // (end of range, level inside it) of the groups and range-skip nodes around a record
+        std::vector<const RtNode *> list_q;        // per level: the first node of the list being walked that carries the list's q
         size_t groups = 0;
         for (size_t i = 0; i + 1 < per_table; ++i) {
             const RtNode &n = tab[i];
@@ -92,6 +93,14 @@ void feed(const std::string &text, Tally &tally) {
             const int inside = open.empty() ? 0 : open.back().second;
             if ((size_t)n.skip > limit) fail("its range ends after the range it stands in", t * per_table + i);
             if (level != inside) fail("its level is not that of the list it stands in", t * per_table + i);
+            // range-skip nodes that claim their sibling list's common q must all hold the same one, bit for bit
+            if (list_q.size() <= (size_t)level + 1) list_q.resize((size_t)level + 2, nullptr);
+            for (size_t l = (size_t)level + 1; l < list_q.size(); ++l) list_q[l] = nullptr;  // deeper lists have ended
+            if (kind == RT_SKIPBOX && (n.tag & RT_NODE_LIST_Q)) {
+                if (n.xform != RT_SKIP_CONES) fail("a list's q on a node without cones below it", t * per_table + i);
+                if (!list_q[(size_t)level]) list_q[(size_t)level] = &n;
+                else if (std::memcmp(list_q[(size_t)level]->inv, n.inv, 6 * sizeof(double)) != 0) fail("two q's in one list that claim to be the list's", t * per_table + i);
+            }
             if (kind == RT_GROUP) {
                 groups++;
                 open.emplace_back((size_t)n.skip, level + 1);
