@@ -1095,6 +1095,17 @@ def test_full_4k_frame(gpu, rt, orc):
     assert np.array_equal(acc, img)
 
 
+def test_which_build_of_the_render_kernel_serves_which_world(gpu, rt):
+    """rt_scene_info.kernel_build: a table of leaves for the book's flat scenes, the build without cone directions for
+    chapter_14 (groups, spheres and cylinders), the general one for the generated hierarchy (cones under its
+    range-skip nodes)."""
+    from raytracer_rs_amd import synthetic
+
+    assert rt.SceneFile.from_file(scene_path("chapter_11")).build_world().scene().info().kernel_build == 0
+    assert rt.SceneFile.from_file(scene_path("chapter_14")).build_world().scene().info().kernel_build == 2
+    assert rt.SceneFile.from_str(synthetic.large_scene(64, 36)).build_world().scene().info().kernel_build == 1
+
+
 def test_full_hd_world_with_shadows(gpu, rt, orc):
     """chapter_7_and_8 (six spheres, point light, shadow rays) at 1920x1080, the size the benchmark configuration
     names: whole frame against the oracle, every counter, and exactly two rays per pixel only where geometry is hit."""
