@@ -4,7 +4,18 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step is one whole frame.  With N ranks (one process per GPU) the frame's rows are cut into 16-row bands dealt
+A step is one whole frame.  `--gpus N` uses N GPUs however the script is started:
+  * started plainly (no WORLD_SIZE in the environment) with N > 1, ONE process drives all N GPUs through the
+    library's rt_multi_* entry points: a worker thread per GPU, bands of rows taken from a shared atomic cursor as
+    the GPUs become free (dynamic stealing), two bands in flight per GPU, finished bands collected on GPU 0 with RCCL
+    (or peer copies) while other GPUs still render.  The measurement runs in a child process that the parent watches:
+    if the RCCL collection fails or stalls, the run is repeated with peer copies and the line says so.  Fewer than N
+    visible GPUs is an error (RT_BENCH_DEVICES=0,0 lists device ordinals explicitly, e.g. to rehearse two workers on one
+    GPU).
+  * started by torchrun, one process per GPU over torch.distributed, as described next.
+`config.workload` says which of the two ran.
+
+With N ranks (one process per GPU) the frame's rows are cut into 16-row bands dealt
 round-robin to the ranks (band b -> rank b % N; band cost varies from ~1 ray/px in the sky to ~30 rays/px on the glass,
 and the fine interleave evens that out); every rank renders its bands with the HIP library into device memory as the
 8-bit frame a PPM is written from (canvas.rs:123-130 applied by the render kernel; `--frame f64` keeps the f64 canvas
@@ -106,9 +117,10 @@ def device_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def committed_traffic() -> dict:
-    """HBM bytes per launch of the headline kernel from the committed PMC passes -- only while the kernel sources are
-    the ones that were profiled (their hash travels with the figure)."""
+def committed_pmc(config: str) -> dict:
+    """HBM bytes and executed f64 flops per launch of a configuration's render kernel from the committed PMC passes
+    (profiles/pmc_traffic.json, one entry per configuration) -- only while the kernel sources are the ones that were
+    profiled (their hash travels with the figures)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
@@ -116,9 +128,12 @@ def committed_traffic() -> dict:
     except Exception:
         return {"traffic": None, "traffic_note": "no committed PMC summary"}
     if t.get("source_sha256") != device_source_hash():
-        return {"traffic": None, "traffic_note": f"profiles/{t.get('profile', '?')} was taken on other kernel sources; not carried over"}
-    return {"traffic": t.get("hbm_bytes_per_launch"), "traffic_profile": t.get("profile"),
-            "executed_flops": t.get("executed_f64_flops_per_launch")}
+        return {"traffic": None, "traffic_note": "profiles/pmc_traffic.json was taken on other kernel sources; not carried over"}
+    e = t.get("configs", {}).get(config)
+    if not e:
+        return {"traffic": None, "traffic_note": f"no committed PMC passes for {config}"}
+    return {"traffic": e.get("hbm_bytes_per_launch"), "traffic_profile": e.get("profile"),
+            "executed_flops": e.get("executed_f64_flops_per_launch")}
 
 
 def kernel_name(scene) -> str:
@@ -126,8 +141,13 @@ def kernel_name(scene) -> str:
     return {0: "render_kernel<false, 0, false>", 2: "render_kernel<false, 2, true>"}.get(info.kernel_build, "render_kernel<false, 1, true>")
 
 
-def time_config(scene, cam, stream, reps: int, quantized: bool) -> dict:
-    """Rays, algorithmic flops and GPU time of one configuration on one GPU (frame stays in HBM)."""
+def time_config(scene, cam, stream, reps: int, quantized: bool, config: str = None, peak: dict = None) -> dict:
+    """Rays, flops and GPU time of one configuration on one GPU (frame stays in HBM).  Two flop figures, never mixed:
+    the REFERENCE's work for the same rays (every ray against every object of every list it enters; what `frac` prices,
+    as the roofline contract asks) and the f64 flops the kernel EXECUTED (PMC passes committed under profiles/, carried
+    only while the kernel sources are unchanged) -- range-skip boxes, balls and sign tests spare the kernel part of
+    the reference's work, so on scenes with groups the first is a speed-up over the reference's algorithm, not a
+    hardware utilisation."""
     W, H = cam.hsize, cam.vsize
     buf = torch.empty(W * H * 3, dtype=torch.uint8 if quantized else torch.float64, device="cuda")
     st = scene.render_device(cam, buf.data_ptr(), None, None, stream, True, False, quantized)
@@ -144,11 +164,39 @@ def time_config(scene, cam, stream, reps: int, quantized: bool) -> dict:
     kernel_ms = sum(t[1] for t in times) / len(times)
     ordering_ms = sum(t[0] for t in times) / len(times)
     flops = algorithmic_flops(counts)
-    return {"rays": counts["rays"], "rays_per_pixel": round(counts["rays"] / (W * H), 3), "ms_per_frame": round(wall_ms, 4),
-            "kernel_ms": round(kernel_ms, 4), "tile_ordering_ms": round(ordering_ms, 4),
-            "mrays_per_s": round(counts["rays"] / wall_ms / 1e3, 1), "algorithmic_flops": flops,
-            "achieved_tflops": round(flops / (kernel_ms * 1e-3) / 1e12, 3),
-            "frac": round(flops / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 4), "kernel": kernel_name(scene)}
+    ref_tf = flops / (kernel_ms * 1e-3) / 1e12
+    out = {"rays": counts["rays"], "rays_per_pixel": round(counts["rays"] / (W * H), 3), "ms_per_frame": round(wall_ms, 4),
+           "kernel_ms": round(kernel_ms, 4), "tile_ordering_ms": round(ordering_ms, 4),
+           "mrays_per_s": round(counts["rays"] / wall_ms / 1e3, 1), "algorithmic_flops": flops,
+           "reference_work_tflops": round(ref_tf, 3),
+           "frac": round(ref_tf / FP64_VECTOR_PEAK_TFLOPS, 4), "kernel": kernel_name(scene)}
+    if peak:
+        out["frac_reference_work_of_measured_unfused"] = round(ref_tf / peak["unfused"], 4)
+    if config:
+        pmc = committed_pmc(config)
+        out["hbm_bytes"] = pmc.get("traffic")
+        if pmc.get("executed_flops"):
+            ex_tf = pmc["executed_flops"] / (kernel_ms * 1e-3) / 1e12
+            out["executed_flops"] = pmc["executed_flops"]
+            out["executed_tflops"] = round(ex_tf, 3)
+            out["frac_executed"] = round(ex_tf / FP64_VECTOR_PEAK_TFLOPS, 4)
+            if peak:
+                out["frac_executed_of_measured_unfused"] = round(ex_tf / peak["unfused"], 4)
+            out["pmc_profile"] = pmc.get("traffic_profile")
+        else:
+            out["pmc_note"] = pmc.get("traffic_note")
+    return out
+
+
+def ppm_encode_ms(scene, cam) -> float:
+    """Canvas::to_ppm_string (canvas.rs:44-90) for the configuration's frame: the linear-time P3 writer on the host,
+    one call, frame already in host memory.  Not part of ms/frame (reported beside it)."""
+    img, _ = scene.render(cam)
+    t0 = time.perf_counter()
+    text = rt.Canvas(cam.hsize, cam.vsize, img).to_ppm_string()
+    dt = (time.perf_counter() - t0) * 1e3
+    del text, img
+    return round(dt, 1)
 
 
 def cpu_baseline(scene_path, width: int, height: int, seconds_target: float = 12.0, scene_text: str = None) -> dict:
@@ -207,6 +255,177 @@ def cpu_baseline(scene_path, width: int, height: int, seconds_target: float = 12
     return out
 
 
+def bench_devices(args) -> list:
+    """Device ordinals of the single-process several-GPU run: RT_BENCH_DEVICES, else 0 .. N-1 (all of which must exist)."""
+    listed = os.environ.get("RT_BENCH_DEVICES")
+    if listed:
+        return [int(v) for v in listed.split(",") if v.strip() != ""]
+    visible = torch.cuda.device_count()
+    if visible < args.gpus:
+        print(f"bench.py --gpus {args.gpus}: only {visible} GPU(s) visible to this process "
+              f"(RT_BENCH_DEVICES=0,0,... rehearses several workers on fewer GPUs)", file=sys.stderr, flush=True)
+        raise SystemExit(4)
+    return list(range(args.gpus))
+
+
+def workload_of(args):
+    """(SceneFile, scene path or None, name, width, height) of the run."""
+    if args.scene:
+        sf, scene_path, name = rt.SceneFile.from_file(args.scene), args.scene, os.path.basename(args.scene)
+        width, height = args.width or 3840, args.height or 2160
+    else:
+        sf, scene_path = scene_file_of(args.config)
+        name, width, height = CONFIGS[args.config]
+        width, height = args.width or width, args.height or height
+    return sf, scene_path, name, width, height
+
+
+def data_note(args, name: str) -> str:
+    """The `data` field: nothing here is measured data; the scenes are the reference's own files or generated."""
+    if args.scene:
+        return f"synthetic (scene file {name}; no datasets on this path)"
+    if args.config == "c5":
+        return "synthetic (scene generated by raytracer_rs_amd.synthetic.large_scene, seed 0x5EED0001, in the reference's TOML schema)"
+    return (f"synthetic in the sense that no dataset exists for this path: the reference's own scene file scenes/{name}.toml "
+            f"(byte-identical copy under tests/golden/scenes/), camera resized to the benchmark's frame")
+
+
+def run_multi_parent(args) -> None:
+    """bench.py --gpus N without a launcher: runs the measurement in a child process (this one never touches a GPU)
+    and watches it; a failed or stalled RCCL collection is repeated with peer copies."""
+    import subprocess
+
+    base = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + ["--multi-child"]
+    limit = float(os.environ.get("RT_BENCH_CHILD_TIMEOUT", "420"))
+    attempts = [dict()] if os.environ.get("RT_MULTI_GATHER") else [dict(), dict(RT_MULTI_GATHER="copy")]
+    note = None
+    for k, extra in enumerate(attempts):
+        env = dict(os.environ, **extra)
+        if note:
+            env["RT_BENCH_NOTE"] = note
+        try:
+            done = subprocess.run(base, env=env, capture_output=True, text=True, timeout=limit, start_new_session=True)
+        except subprocess.TimeoutExpired as e:
+            note = f"first attempt (gather via RCCL) did not finish within {limit:.0f} s and was stopped"
+            sys.stderr.write((e.stderr or b"").decode(errors="replace")[-2000:] if isinstance(e.stderr, bytes) else (e.stderr or "")[-2000:])
+            continue
+        sys.stderr.write(done.stderr[-4000:])
+        if done.returncode == 0 and done.stdout.strip():
+            print(done.stdout.strip().splitlines()[-1], flush=True)
+            return
+        note = f"first attempt (gather via RCCL) exited with status {done.returncode}"
+        if k + 1 == len(attempts) or done.returncode in (3, 4):  # a differing frame or too few GPUs: nothing a repeat would cure
+            raise SystemExit(done.returncode or 1)
+    raise SystemExit(1)
+
+
+def run_multi_child(args) -> None:
+    """One process, N GPUs: rt_multi_* (worker thread per GPU, shared band cursor, two bands in flight per GPU,
+    collection on devices[0] overlapped with rendering)."""
+    devices = bench_devices(args)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
+    first = devices[0]
+    torch.cuda.set_device(first)
+    dev = torch.device("cuda", first)
+    sf, scene_path, name, width, height = workload_of(args)
+    cam = sf.build_camera(width, height)
+    world = sf.build_world()
+    W, H = cam.hsize, cam.vsize
+    u8 = args.frame == "u8"
+    t_create = time.perf_counter()
+    multi = world.multi_scene(devices)
+    create_ms = (time.perf_counter() - t_create) * 1e3
+    frame = torch.empty(W * H * 3, dtype=torch.uint8 if u8 else torch.float64, device=dev)
+    band_rows = int(os.environ.get("RT_BENCH_BAND_ROWS", "0"))
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    st = multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, stats=True, quantized=u8)
+    counts = st.as_dict()
+    rays_frame = counts["rays"]
+    flops = algorithmic_flops(counts)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.1:
+        multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, quantized=u8)
+    prewarm_s = time.perf_counter() - t_pre
+    for _ in range(args.warmup):
+        multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, quantized=u8)
+    sync_all()
+    render_ms, gather_ms, taken, worker_ms = [], [], [0] * len(devices), [0.0] * len(devices)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, quantized=u8)
+        render_ms.append(st.kernel_ms)
+        gather_ms.append(st.gather_ms)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    # one more (untimed) frame for the per-worker figures
+    multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, quantized=u8)
+    taken, worker_ms, info = multi.bands_taken(), multi.worker_ms(), multi.info()
+
+    scene = world.scene(first)
+    stream = torch.cuda.current_stream().cuda_stream
+    if args.check:
+        whole = torch.zeros(H * W * 3, dtype=torch.float64, device=dev)
+        scene.render_device(cam, whole.data_ptr(), None, None, stream, False)
+        if u8:
+            q = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
+            rt.quantize_device(whole.data_ptr(), whole.numel(), q.data_ptr(), stream)
+            whole = q
+        torch.cuda.synchronize()
+        same = torch.equal(frame, whole)
+        print(f"check: collected frame {'equals' if same else 'DIFFERS FROM'} the single-GPU frame", file=sys.stderr, flush=True)
+        if not same:
+            raise SystemExit(3)
+    # the same frame through the one-GPU entry point on devices[0], for the ratio
+    single = time_config(scene, cam, stream, 10, u8)
+
+    n_distinct = len(set(devices))
+    ms_per_step = elapsed / max(1, args.steps) * 1e3
+    achieved_tf = flops / (ms_per_step * 1e-3) / 1e12
+    headline = (args.config == "c3" and not args.scene and (W, H) == (3840, 2160))
+    line = {
+        "metric": "Mrays/s, 3840x2160 chapter_11 scene" if headline else f"Mrays/s, {W}x{H} frame of {name}",
+        "value": round(rays_frame * args.steps / elapsed / 1e6, 2),
+        "unit": "Mrays/s",
+        "n_gpus": n_distinct, "workers": len(devices), "devices": devices,
+        "steps": args.steps, "warmup": args.warmup, "prewarm_s": round(prewarm_s, 3),
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": data_note(args, name),
+        "config": {"workload": f"{name} at {W}x{H}, depth 5; ONE process, a worker thread per GPU, {info['n_bands']} bands of "
+                               f"{info['band_rows']} rows taken from a shared atomic cursor (two in flight per GPU), f64 colours -> "
+                               + ("8-bit frame (canvas.rs:123-130 applied by the render kernel) " if u8 else "f64 frame ")
+                               + f"assembled on GPU {first} ({info['gather']} collection)",
+                   "path": "single process, rt_multi_render_device",
+                   "rays_per_frame": rays_frame, "rays_per_pixel": round(rays_frame / (W * H), 3)},
+        "gather": info["gather"], "rccl_ranks": info["rccl_ranks"], "gather_note": info["note"],
+        "bands": info["n_bands"], "band_rows": info["band_rows"], "bands_taken": taken,
+        "worker_render_ms": [round(v, 4) for v in worker_ms],
+        "render_ms": round(sum(render_ms) / max(1, len(render_ms)), 4),
+        "gather_ms": round(sum(gather_ms) / max(1, len(gather_ms)), 4),
+        "multi_create_ms": round(create_ms, 1),
+        "single_gpu_same_run": {"ms_per_frame": single["ms_per_frame"], "kernel_ms": single["kernel_ms"], "mrays_per_s": single["mrays_per_s"],
+                                "note": f"rt_render_device on GPU {first} alone, same frame, same process"},
+        "roofline": {"bound": "valu_f64", "achieved": round(achieved_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS * n_distinct,
+                     "unit": "TFLOP/s", "frac": round(achieved_tf / (FP64_VECTOR_PEAK_TFLOPS * n_distinct), 4),
+                     "algorithmic_flops_per_frame": flops, "traffic": None,
+                     "note": "whole job: the frame's algorithmic flops over the wall-clock time per frame (bands of several "
+                             "launches per GPU, collection included), against the FP64 vector peak of the GPUs used"},
+        "cpu_baseline": None,
+    }
+    if os.environ.get("RT_BENCH_NOTE"):
+        line["note"] = os.environ["RT_BENCH_NOTE"] + "; this line is the repeat with peer copies"
+    print(json.dumps(line), flush=True)
+    multi.close()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,7 +444,17 @@ def main() -> None:
     ap.add_argument("--frame", choices=["f64", "u8"], default="u8",
                     help="what rank 0 collects: the 8-bit frame a PPM is written from, quantised on each GPU "
                          "(canvas.rs:123-130) before the gather (default), or the f64 canvas itself (8x the bytes)")
+    ap.add_argument("--multi-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and (args.gpus > 1 or os.environ.get("RT_BENCH_DEVICES")):
+        # one process for all GPUs; the measuring child is started by a parent that never touches a GPU itself
+        if args.multi_child:
+            run_multi_child(args)
+        else:
+            run_multi_parent(args)
+        return
 
     if os.environ.get("RT_BENCH_WATCHDOG"):  # developer aid: dump every thread's stack and exit if the run stalls
         import faulthandler
@@ -252,16 +481,12 @@ def main() -> None:
         else:
             dist.init_process_group(backend)
 
-    if args.scene:
-        sf, scene_path, name = rt.SceneFile.from_file(args.scene), args.scene, os.path.basename(args.scene)
-        width, height = args.width or 3840, args.height or 2160
-    else:
-        sf, scene_path = scene_file_of(args.config)
-        name, width, height = CONFIGS[args.config]
-        width, height = args.width or width, args.height or height
+    sf, scene_path, name, width, height = workload_of(args)
     cam = sf.build_camera(width, height)
     world = sf.build_world()
+    t_create = time.perf_counter()
     scene = world.scene(device_index)
+    scene_create_ms = (time.perf_counter() - t_create) * 1e3
     W, H = cam.hsize, cam.vsize
     # device buffers: my bands (padded to equal size so the gather is uniform) and, on rank 0, the frame
     u8 = args.frame == "u8"
@@ -313,6 +538,7 @@ def main() -> None:
     # The GPU takes ~40 ms of continuous work to reach its steady clocks (the first frames of a run are 15 % slower):
     # whatever --warmup says, frames are rendered for a tenth of a second before anything is timed.  On one GPU that
     # happens here; with several ranks after the --warmup steps, as whole steps.
+    prewarm_s = 0.0
     if not multi:
         t_pre = time.perf_counter()
         k_pre = 0
@@ -322,6 +548,7 @@ def main() -> None:
             if k_pre % 8 == 0:
                 torch.cuda.synchronize()
         torch.cuda.synchronize()
+        prewarm_s = time.perf_counter() - t_pre
     for k in range(args.warmup):
         step(k)
     if multi:
@@ -338,6 +565,7 @@ def main() -> None:
             spent = torch.tensor([time.perf_counter() - t_pre], dtype=torch.float64, device=reduce_dev)
             dist.all_reduce(spent, op=dist.ReduceOp.MAX)
             if spent.item() >= 0.1:
+                prewarm_s = spent.item()
                 break
     bg.finish()
     if multi:
@@ -385,16 +613,19 @@ def main() -> None:
             "value": round(rays_frame * args.steps / elapsed / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "prewarm_s": round(prewarm_s, 3),  # frames rendered before the --warmup frames, until the GPU's clocks have settled
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"{name} at {W}x{H}, depth 5, {BAND_ROWS}-row bands "
-                                   f"round-robin over {world_size} GPU(s), f64 colours -> "
+            "data": data_note(args, name),
+            "config": {"workload": (f"{name} at {W}x{H}, depth 5, {BAND_ROWS}-row bands round-robin over {world_size} ranks "
+                                    f"(one process per GPU, torch.distributed), f64 colours -> " if multi else
+                                    f"{name} at {W}x{H}, depth 5, whole frame in one launch on one GPU, f64 colours -> ")
                                    + ("8-bit frame (canvas.rs:123-130 applied by the render kernel) " if u8 else "f64 frame ")
-                                   + "collected on rank 0",
+                                   + ("collected on rank 0 with one RCCL gather per frame" if multi else "in HBM"),
+                       "path": "one process per GPU, rt_render_device + torch.distributed.gather" if multi else "single GPU, rt_render_device",
                        "rays_per_frame": rays_frame, "rays_per_pixel": round(rays_frame / (W * H), 3),
                        "kernel_ms_max_over_ranks": round(kernel_ms_max, 4)},
             "roofline": {"bound": "valu_f64", "achieved": round(achieved_tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS,
@@ -406,21 +637,43 @@ def main() -> None:
                          "algorithmic_flops_per_launch": my_flops,
                          "note": "FP64 vector ALU is the bounding unit (no dense contraction, scene cache-resident); "
                                  "peak counts an FMA as 2 flops, the kernel is built without FMA contraction to keep "
-                                 "the reference's rounding, so its own ceiling is half of peak; algorithmic flops are "
+                                 "the reference's rounding, so its own ceiling is half of peak; `achieved` and `frac` price "
                                  "the REFERENCE's work for the same rays (every ray against every object, 33 flops per "
-                                 "ray transform): the kernel executes 9 per scale-and-translate inverse and skips a "
-                                 "sphere or plane that no ray of a wave can hit (executed_flops is what it issued)"},
+                                 "ray transform), as the roofline contract asks; the kernel executes 9 per "
+                                 "scale-and-translate inverse and skips a sphere or plane that no ray of a wave can hit: "
+                                 "executed_flops (PMC) is what it issued and frac_executed prices that"},
         }
         # the committed PMC figures are per launch of the WHOLE frame: they describe a one-GPU run only
-        line["roofline"].update(committed_traffic() if headline and u8 and world_size == 1 else {"traffic": None})
+        line["roofline"].update(committed_pmc(args.config) if headline and u8 and world_size == 1 else {"traffic": None})
+        if line["roofline"].get("executed_flops") and kernel_ms > 0:
+            ex_tf = line["roofline"]["executed_flops"] / (kernel_ms * 1e-3) / 1e12
+            line["roofline"]["executed_tflops"] = round(ex_tf, 3)
+            line["roofline"]["frac_executed"] = round(ex_tf / FP64_VECTOR_PEAK_TFLOPS, 4)
         if world_size == 1 and not multi:
+            line["scene_create_ms"] = round(scene_create_ms, 2)  # flatten + upload (rt_scene_create), outside ms/frame
             peak = measured_fp64_peak()
             if peak:
                 line["roofline"]["peak_measured_fma"] = round(peak["fma"], 2)
                 line["roofline"]["peak_measured_unfused"] = round(peak["unfused"], 2)
-                line["roofline"]["frac_of_measured_fma"] = round(achieved_tf / peak["fma"], 4)
-                line["roofline"]["frac_of_measured_unfused"] = round(achieved_tf / peak["unfused"], 4)
+                line["roofline"]["frac_reference_work_of_measured_fma"] = round(achieved_tf / peak["fma"], 4)
+                line["roofline"]["frac_reference_work_of_measured_unfused"] = round(achieved_tf / peak["unfused"], 4)
+                if line["roofline"].get("executed_tflops"):
+                    line["roofline"]["frac_executed_of_measured_unfused"] = round(line["roofline"]["executed_tflops"] / peak["unfused"], 4)
             if not args.no_others:
+                line["ppm_encode_ms"] = ppm_encode_ms(scene, cam)  # Canvas::to_ppm_string on the host, outside ms/frame
+                # the same frame through the several-GPU entry point with one worker on this GPU: what that path costs
+                # beyond rt_render_device (one band = the whole frame; the call returns when the frame is complete)
+                m1 = world.multi_scene([device_index])
+                probe = torch.empty(W * H * 3, dtype=torch.uint8 if u8 else torch.float64, device=dev)
+                for _ in range(5):
+                    m1.render_device(cam, probe.data_ptr(), quantized=u8)
+                t1 = time.perf_counter()
+                n_m1 = max(10, args.steps)
+                for _ in range(n_m1):
+                    m1.render_device(cam, probe.data_ptr(), quantized=u8)
+                line["multi_single_gpu_ms"] = round((time.perf_counter() - t1) / n_m1 * 1e3, 4)
+                m1.close()
+                del probe
                 f64 = time_config(scene, cam, stream, 20, False)
                 line["f64_frame"] = {"ms_per_step": f64["ms_per_frame"], "value": f64["mrays_per_s"], "kernel_ms": f64["kernel_ms"],
                                      "note": "the same frame stored as the f64 canvas (Canvas.pixels, 24 B per pixel) in HBM"}
@@ -462,13 +715,16 @@ def main() -> None:
                     if cfg == args.config and not args.scene and (W, H) == CONFIGS[cfg][1:]:
                         continue
                     osf, _ = scene_file_of(cfg)
-                    oscene = osf.build_world().scene(device_index)
+                    oworld = osf.build_world()
+                    t1 = time.perf_counter()
+                    oscene = oworld.scene(device_index)
+                    ocreate_ms = (time.perf_counter() - t1) * 1e3
                     ocam = osf.build_camera(CONFIGS[cfg][1], CONFIGS[cfg][2])
-                    r = time_config(oscene, ocam, stream, 20 if cfg != "c5" else 5, True)
+                    r = time_config(oscene, ocam, stream, 20 if cfg != "c5" else 5, True, cfg, peak)
                     r["config"] = cfg
                     r["workload"] = f"{CONFIGS[cfg][0]} at {CONFIGS[cfg][1]}x{CONFIGS[cfg][2]}, depth 5, 8-bit frame in HBM"
-                    if peak:
-                        r["frac_of_measured_unfused"] = round(r["achieved_tflops"] / peak["unfused"], 4)
+                    r["scene_create_ms"] = round(ocreate_ms, 2)
+                    r["ppm_encode_ms"] = ppm_encode_ms(oscene, ocam)
                     others.append(r)
                     oscene.close()
                 line["other_configs"] = others

@@ -5,7 +5,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RT_ABI_VERSION: c_int = 3;
+pub const RT_ABI_VERSION: c_int = 4;
 pub const RT_OK: c_int = 0;
 pub const RT_ERR_INVALID_ARGUMENT: c_int = -1;
 pub const RT_ERR_NOT_INVERTIBLE: c_int = -2;
@@ -115,6 +115,7 @@ pub struct rt_stats {
     pub refract_setups: u64,
     pub schlick: u64,
     pub kernel_ms: f64,
+    pub gather_ms: f64,
 }
 
 #[repr(C)]
@@ -141,6 +142,22 @@ pub struct rt_scene_info {
     pub device_bytes: u64,
     pub device: i32,
     pub kernel_build: i32,
+}
+
+pub const RT_GATHER_NONE: i32 = 0;
+pub const RT_GATHER_RCCL: i32 = 1;
+pub const RT_GATHER_COPY: i32 = 2;
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rt_multi_info {
+    pub n_workers: u32,
+    pub n_devices: u32,
+    pub gather: i32,
+    pub rccl_ranks: u32,
+    pub band_rows: u32,
+    pub n_bands: u32,
+    pub note: [c_char; 160],
 }
 
 #[repr(C)]
@@ -191,6 +208,8 @@ extern "C" {
     pub fn rt_multi_render_device(multi: *mut rt_multi, camera: *const rt_camera_desc, opts: *const rt_render_opts, frame_device: *mut c_void, stats: *mut rt_stats) -> c_int;
     pub fn rt_multi_render(multi: *mut rt_multi, camera: *const rt_camera_desc, opts: *const rt_render_opts, rgb: *mut f64, stats: *mut rt_stats) -> c_int;
     pub fn rt_multi_bands_taken(multi: *const rt_multi, per_worker: *mut u32, n: u32) -> c_int;
+    pub fn rt_multi_worker_ms(multi: *const rt_multi, per_worker: *mut f64, n: u32) -> c_int;
+    pub fn rt_multi_get_info(multi: *const rt_multi, out: *mut rt_multi_info) -> c_int;
 
     pub fn rt_color_at(scene: *const rt_scene, rays: *const f64, n: u32, remaining: i32, colors: *mut f64, stats: *mut rt_stats) -> c_int;
     pub fn rt_intersect(scene: *const rt_scene, rays: *const f64, n: u32, t: *mut f64, object: *mut i32) -> c_int;

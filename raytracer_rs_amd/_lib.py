@@ -67,7 +67,8 @@ class Stats(C.Structure):
                 ("refract", C.c_uint64), ("prim_tests", C.c_uint64 * 5), ("prim_hits", C.c_uint64 * 5),
                 ("aabb_tests", C.c_uint64), ("ray_transforms", C.c_uint64), ("shades", C.c_uint64),
                 ("lit", C.c_uint64), ("specular", C.c_uint64), ("patterns", C.c_uint64),
-                ("refract_setups", C.c_uint64), ("schlick", C.c_uint64), ("kernel_ms", C.c_double)]
+                ("refract_setups", C.c_uint64), ("schlick", C.c_uint64), ("kernel_ms", C.c_double),
+                ("gather_ms", C.c_double)]
 
     COUNT_FIELDS = ("rays", "primary", "shadow", "reflect", "refract", "prim_tests", "prim_hits", "aabb_tests",
                     "ray_transforms", "shades", "lit", "specular", "patterns", "refract_setups", "schlick")
@@ -93,6 +94,14 @@ class RenderOpts(C.Structure):
                 ("band_first", C.c_uint32), ("band_step", C.c_uint32), ("flags", C.c_uint32)]
 
 
+class MultiInfo(C.Structure):
+    _fields_ = [("n_workers", C.c_uint32), ("n_devices", C.c_uint32), ("gather", C.c_int32), ("rccl_ranks", C.c_uint32),
+                ("band_rows", C.c_uint32), ("n_bands", C.c_uint32), ("note", C.c_char * 160)]
+
+
+GATHER_NAMES = {0: "none", 1: "rccl", 2: "copy"}
+
+
 class SceneInfo(C.Structure):
     _fields_ = [("n_objects", C.c_uint32), ("n_leaves", C.c_uint32), ("n_groups", C.c_uint32),
                 ("max_nesting", C.c_uint32), ("device_bytes", C.c_uint64), ("device", C.c_int32), ("kernel_build", C.c_int32)]
@@ -116,6 +125,8 @@ SIGNATURES = {
     "rt_multi_render_device": (C.c_int, [C.c_void_p, _P(CameraDesc), _P(RenderOpts), C.c_void_p, _P(Stats)]),
     "rt_multi_render": (C.c_int, [C.c_void_p, _P(CameraDesc), _P(RenderOpts), _P(C.c_double), _P(Stats)]),
     "rt_multi_bands_taken": (C.c_int, [C.c_void_p, _P(C.c_uint32), C.c_uint32]),
+    "rt_multi_worker_ms": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32]),
+    "rt_multi_get_info": (C.c_int, [C.c_void_p, _P(MultiInfo)]),
     "rt_color_at": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_int32, _P(C.c_double), _P(Stats)]),
     "rt_intersect": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, _P(C.c_double), _P(C.c_int32)]),
     "rt_intersect_all": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_uint32, _P(C.c_uint32), _P(C.c_double),

@@ -526,6 +526,19 @@ class MultiScene:
         L.check(L.lib().rt_multi_bands_taken(self._h, arr, len(self.devices)))
         return list(arr)
 
+    def worker_ms(self) -> List[float]:
+        """When each worker's last kernel of the last call had finished, in ms since the call began."""
+        arr = (C.c_double * len(self.devices))()
+        L.check(L.lib().rt_multi_worker_ms(self._h, arr, len(self.devices)))
+        return list(arr)
+
+    def info(self) -> dict:
+        """rt_multi_get_info: workers, distinct GPUs, how bands are collected, the band plan of the last call."""
+        mi = L.MultiInfo()
+        L.check(L.lib().rt_multi_get_info(self._h, C.byref(mi)))
+        return {"n_workers": mi.n_workers, "n_devices": mi.n_devices, "gather": L.GATHER_NAMES.get(mi.gather, str(mi.gather)),
+                "rccl_ranks": mi.rccl_ranks, "band_rows": mi.band_rows, "n_bands": mi.n_bands, "note": mi.note.decode(errors="replace")}
+
 
 def _check_frame(out: np.ndarray, camera: "Camera") -> None:
     """A caller-provided frame must be what the C side writes: float64, C-contiguous, [vsize, hsize, 3]."""

@@ -42,6 +42,9 @@ struct rt_scene {
     uint32_t *d_tiles = nullptr;  // tile-ordering scratch of launch_render, grown on demand
     size_t tiles_cap = 0;         // in 32-bit words
     bool uneven = false;          // tiles differ in cost by more than a shadow ray: ordering them pays
+    bool order_valid = false;     // d_tiles holds the launch order for (order_cam, order_rows)
+    RtCameraDev order_cam{};
+    uint32_t order_rows[5] = {};
     hipEvent_t marks[32][3] = {};  // event triples of the launches made with RT_RENDER_TIMED, used round-robin
     uint32_t timed_launches = 0;
     RenderPipe pipe;
@@ -161,6 +164,33 @@ int render_rows(const rt_scene *scene, const rt_camera_desc *camera, const rt_re
 }  // namespace
 
 int rt::capi_set_error(int code, const std::string &msg) { return set_error(code, msg); }
+
+static int render_device_impl(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
+                              double *rgb_device, rt_stats *stats, bool accumulate);
+
+int rt::capi_render_device_counting(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts, double *rgb_device) {
+    return render_device_impl(scene, camera, opts, rgb_device, nullptr, true);
+}
+
+int rt::capi_counters_reset(const rt_scene *scene, void *stream) {
+    if (!scene) return set_error(RT_ERR_INVALID_ARGUMENT, "scene must not be NULL");
+    DeviceGuard guard(scene->device);
+    if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+    HIP_TRY(hipMemsetAsync(scene->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), (hipStream_t)stream));
+    return RT_OK;
+}
+
+int rt::capi_counters_read(const rt_scene *scene, void *stream, rt_stats *stats) {
+    if (!scene || !stats) return set_error(RT_ERR_INVALID_ARGUMENT, "scene and stats must not be NULL");
+    DeviceGuard guard(scene->device);
+    if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+    unsigned long long c[RT_NUM_COUNTERS];
+    HIP_TRY(hipMemcpyAsync(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    std::memset(stats, 0, sizeof *stats);
+    stats_from_counters(c, stats);
+    return RT_OK;
+}
 
 extern "C" {
 
@@ -286,8 +316,18 @@ static bool tile_order_enabled() {
     static const bool enabled = [] { const char *e = getenv("RT_TILE_ORDER"); return !(e && e[0] == '0'); }();
     return enabled;
 }
-static hipError_t tile_scratch(const rt_scene *scene_c, const rt_camera_desc *camera, const rt::RowMap &rows, uint32_t **out) {
+static bool tile_order_cache_enabled() {
+    static const bool enabled = [] { const char *e = getenv("RT_TILE_ORDER_CACHE"); return !(e && e[0] == '0'); }();
+    return enabled;
+}
+// `cached` (optional): set when the scratch already holds the launch order of exactly these rows seen through exactly
+// this camera -- the order is a function of world, camera and rows only, so a caller that renders the same view again
+// (a frame loop, a benchmark) need not have it worked out again.  Callers that pass nullptr share the scratch between
+// launches over different rows and get no caching.
+static hipError_t tile_scratch(const rt_scene *scene_c, const rt_camera_desc *camera, const rt::RowMap &rows, const RtCameraDev *cam,
+                               uint32_t **out, bool *cached) {
     *out = nullptr;
+    if (cached) *cached = false;
     if (!tile_order_enabled() || rows.n_rows == 0 || !scene_c->uneven) return hipSuccess;
     rt_scene *scene = const_cast<rt_scene *>(scene_c);
     const size_t need = rt::render_scratch_words(camera->hsize, rows.n_rows);
@@ -295,31 +335,48 @@ static hipError_t tile_scratch(const rt_scene *scene_c, const rt_camera_desc *ca
         if (scene->d_tiles) (void)hipFree(scene->d_tiles);
         scene->d_tiles = nullptr;
         scene->tiles_cap = 0;
+        scene->order_valid = false;
         hipError_t e = hipMalloc((void **)&scene->d_tiles, need * sizeof(uint32_t));
         if (e != hipSuccess) return e;
         scene->tiles_cap = need;
     }
     *out = scene->d_tiles;
+    if (!cached || !cam || !tile_order_cache_enabled()) {
+        scene->order_valid = false;
+        return hipSuccess;
+    }
+    const uint32_t key[5] = {rows.row_begin, rows.row_end, rows.n_rows, rows.band_rows, rows.band_pitch};
+    if (scene->order_valid && std::memcmp(&scene->order_cam, cam, sizeof *cam) == 0 && std::memcmp(scene->order_rows, key, sizeof key) == 0) {
+        *cached = true;
+    } else {
+        scene->order_cam = *cam;
+        std::memcpy(scene->order_rows, key, sizeof key);
+        scene->order_valid = true;
+    }
     return hipSuccess;
 }
 
-int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
-                     double *rgb_device, rt_stats *stats) {
+// rt_render_device, and the variant rt_multi uses when it collects statistics: `accumulate` launches the counting
+// kernel so that it adds to the handle's counters as they stand -- no clearing before, no read-back and therefore no
+// host synchronisation after (rt::capi_counters_reset / rt::capi_counters_read bracket a run of such launches).
+static int render_device_impl(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
+                              double *rgb_device, rt_stats *stats, bool accumulate) {
     rt::RowMap rows;
     int depth;
     RtCameraDev cam;
     int rc = render_rows(scene, camera, opts, rows, depth, cam);
     if (rc != RT_OK) return rc;
     if (!rgb_device && rows.n_rows) return set_error(RT_ERR_INVALID_ARGUMENT, "rgb_device must not be NULL");
-    const bool want_stats = opts && opts->collect_stats;
-    if (want_stats && !stats) return set_error(RT_ERR_INVALID_ARGUMENT, "collect_stats needs a stats pointer");
+    const bool want_stats = accumulate || (opts && opts->collect_stats);
+    if (want_stats && !stats && !accumulate) return set_error(RT_ERR_INVALID_ARGUMENT, "collect_stats needs a stats pointer");
     hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
     DeviceGuard guard(scene->device);
     if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
     if (stats) std::memset(stats, 0, sizeof *stats);
-    if (want_stats) HIP_TRY(hipMemsetAsync(scene->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), stream));
+    if (want_stats && !accumulate) HIP_TRY(hipMemsetAsync(scene->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), stream));
     uint32_t *tiles = nullptr;
-    HIP_TRY(tile_scratch(scene, camera, rows, &tiles));
+    bool order_cached = false;
+    HIP_TRY(tile_scratch(scene, camera, rows, &cam, &tiles, &order_cached));
     if (opts && (opts->flags & RT_RENDER_QUANTIZED)) rows.quantized = reinterpret_cast<uint8_t *>(rgb_device);
     hipEvent_t *marks = nullptr;
     if (opts && (opts->flags & RT_RENDER_TIMED)) {
@@ -329,14 +386,19 @@ int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const 
             if (!marks[k]) HIP_TRY(hipEventCreate(&marks[k]));
         mut->timed_launches++;
     }
-    HIP_TRY(rt::launch_render(scene->dev, cam, rows, depth, rgb_device, want_stats ? scene->d_counters : nullptr, tiles, stream, marks));
-    if (want_stats) {
+    HIP_TRY(rt::launch_render(scene->dev, cam, rows, depth, rgb_device, want_stats ? scene->d_counters : nullptr, tiles, stream, marks, order_cached));
+    if (want_stats && !accumulate) {
         unsigned long long c[RT_NUM_COUNTERS];
         HIP_TRY(hipMemcpyAsync(c, scene->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         stats_from_counters(c, stats);
     }
     return RT_OK;
+}
+
+int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
+                     double *rgb_device, rt_stats *stats) {
+    return render_device_impl(scene, camera, opts, rgb_device, stats, false);
 }
 
 int rt_render_device_noalloc(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,
@@ -439,7 +501,7 @@ int rt_render(const rt_scene *scene_c, const rt_camera_desc *camera, const rt_re
     RenderPipe &p = scene->pipe;
     HIP_TRY(pipe_prepare(p, bytes));
     uint32_t *tiles = nullptr;
-    HIP_TRY(tile_scratch(scene, camera, rows, &tiles));
+    HIP_TRY(tile_scratch(scene, camera, rows, nullptr, &tiles, nullptr));
 
     // Groups of packed rows [begin, end): whole bands (band mode) or multiples of the 8-row tile height, at least
     // 8 MB each so that no stage is dominated by its fixed costs.

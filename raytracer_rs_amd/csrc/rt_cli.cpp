@@ -1,11 +1,12 @@
 // rt_render: the command-line face of the library, standing in for the reference's `main` (main.rs:70-184), which
 // loads a scene file, renders it and writes a PPM per chapter.
 //
-//   rt_render <scene.toml> [-o out.ppm] [--width W --height H] [--device D | --devices D0,D1,...] [--depth N] [--stats]
-//   rt_render --all-chapters <scenes_dir> <outputs_dir> [--device D | --devices D0,D1,...]
+//   rt_render <scene.toml> [-o out.ppm] [--width W --height H] [--device D | --devices D0,D1,... [--band-rows R]] [--depth N] [--stats]
+//   rt_render --all-chapters <scenes_dir> <outputs_dir> [--device D | --devices D0,D1,... [--band-rows R]]
 //
 // --devices renders one frame on several GPUs (rt_multi_render: bands of rows taken from a shared cursor; an ordinal
-// may be listed more than once for several workers on one GPU).
+// may be listed more than once for several workers on one GPU); --band-rows sets the height of a band (a multiple of
+// 8, the tile height; default: chosen by the library).
 // The second form reproduces main()'s set of scene-file renders: chapter_5 .. chapter_14 into the reference's
 // output names.  (The chapter 2 and 4 plots of main() draw on a canvas directly and never touch the renderer;
 // JPEG output goes through a third-party encoder: neither is provided.)
@@ -29,6 +30,7 @@ struct Options {
     int device = 0, depth = -1;  // depth < 0: the reference's default budget
     std::vector<int> devices;    // non-empty: render on these GPUs together
     bool stats = false;
+    uint32_t band_rows = 0;      // with --devices: rows per band, 0 = the library's choice
 };
 
 int render_file(const std::string &scene_path, const std::string &out_path, const Options &opt) {
@@ -59,6 +61,7 @@ int render_file(const std::string &scene_path, const std::string &out_path, cons
         ro.collect_stats = opt.stats ? 1 : 0;
         rt_stats st;
         if (!opt.devices.empty()) {
+            ro.band_rows = opt.band_rows;
             if (rt_multi_create(&world, opt.devices.data(), (uint32_t)opt.devices.size(), &multi) != RT_OK) { fail("scene"); break; }
             if (rt_multi_render(multi, &cam, &ro, rgb.data(), &st) != RT_OK) { fail("render"); break; }
         } else {
@@ -67,6 +70,7 @@ int render_file(const std::string &scene_path, const std::string &out_path, cons
         }
         if (rt_canvas_write_ppm(rgb.data(), cam.hsize, cam.vsize, out_path.c_str()) != RT_OK) { fail(out_path.c_str()); break; }
         std::printf("%s -> %s  %ux%u  kernel %.3f ms", scene_path.c_str(), out_path.c_str(), cam.hsize, cam.vsize, st.kernel_ms);
+        if (multi) std::printf("  gather %.3f ms", st.gather_ms);
         if (opt.stats)
             std::printf("  rays %llu (primary %llu, shadow %llu, reflected %llu, refracted %llu)", (unsigned long long)st.rays,
                         (unsigned long long)st.primary, (unsigned long long)st.shadow, (unsigned long long)st.reflect,
@@ -111,16 +115,19 @@ int main(int argc, char **argv) {
                 p = *end == ',' ? end + 1 : end;
             }
         }
+        else if (a == "--band-rows") opt.band_rows = (uint32_t)std::strtoul(value("--band-rows"), nullptr, 10);
         else if (a == "--depth") opt.depth = std::atoi(value("--depth"));
         else if (a == "--stats") opt.stats = true;
         else if (a == "--all-chapters") all = true;
         else if (a == "-h" || a == "--help") pos.clear(), argc = 0;
         else pos.push_back(a);
     }
-    if ((all && pos.size() != 2) || (!all && pos.size() != 1) || (opt.width != 0) != (opt.height != 0)) {
+    if ((all && pos.size() != 2) || (!all && pos.size() != 1) || (opt.width != 0) != (opt.height != 0) || (opt.band_rows && opt.devices.empty()) ||
+        opt.band_rows % 8 != 0) {
         std::fprintf(stderr,
-                     "usage: rt_render <scene.toml> [-o out.ppm] [--width W --height H] [--device D | --devices D0,D1,...] [--depth N] [--stats]\n"
-                     "       rt_render --all-chapters <scenes_dir> <outputs_dir> [--device D | --devices D0,D1,...]\n");
+                     "usage: rt_render <scene.toml> [-o out.ppm] [--width W --height H] [--device D | --devices D0,D1,... [--band-rows R]] [--depth N] [--stats]\n"
+                     "       rt_render --all-chapters <scenes_dir> <outputs_dir> [--device D | --devices D0,D1,... [--band-rows R]]\n"
+                     "       (--band-rows: a multiple of 8, only with --devices)\n");
         return 2;
     }
     if (!all) {

@@ -1945,7 +1945,7 @@ size_t render_scratch_words(uint32_t hsize, uint32_t n_rows) {
 
 hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows_in, int max_depth,
                          double *rgb, unsigned long long *counters, uint32_t *tile_scratch, hipStream_t stream,
-                         hipEvent_t *marks) {
+                         hipEvent_t *marks, bool order_cached) {
     if (rows_in.n_rows == 0 || camera.hsize == 0 || rows_in.band_rows == 0) return hipSuccess;
     const unsigned long long tiles = (unsigned long long)((camera.hsize + 7) / 8) * ((rows_in.n_rows + 7) / 8);
     if (tiles > 0x7fffffffull) return hipErrorInvalidValue;
@@ -1955,7 +1955,9 @@ hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, co
         hipError_t e = hipEventRecord(marks[0], stream);
         if (e != hipSuccess) return e;
     }
-    if (tile_scratch) {
+    if (tile_scratch && order_cached) {
+        rows.tile_list = tile_scratch;  // the order an earlier launch worked out for these very rows and this very camera
+    } else if (tile_scratch) {
         const unsigned tiles_x = (camera.hsize + 7) / 8, tiles_y = (rows.n_tiles + tiles_x - 1) / tiles_x;
         const dim3 cgrid(blocks_for(((tiles_x + 7) / 8) * ((tiles_y + 7) / 8) * 64u));  // one wave per 8x8 block of tiles
         if (scene.max_nesting == 0) classify_tiles_kernel<0><<<cgrid, 256, lds_bytes<0, false>(256), stream>>>(scene, camera, rows, tile_scratch);

@@ -44,9 +44,11 @@ size_t render_scratch_words(uint32_t hsize, uint32_t n_rows);
 // after the render kernel.
 // tile_scratch (render_scratch_words() words, or nullptr) lets the launch order its 8x8 pixel tiles by expected cost,
 // expensive first, which shortens the under-occupied end of the launch; the image does not depend on it.
+// order_cached: tile_scratch still holds the order a previous launch computed for the same scene, camera and rows;
+// the three ordering kernels are not launched again.
 hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows, int max_depth,
                          double *rgb, unsigned long long *counters, uint32_t *tile_scratch, hipStream_t stream,
-                         hipEvent_t *marks = nullptr);
+                         hipEvent_t *marks = nullptr, bool order_cached = false);
 // The tile-ordering scratch that lives in a static device array (one copy per GPU) instead of allocated memory:
 // static_render_scratch_resolve(device) looks its address up once per device -- call it with `device` current, at
 // set-up; static_render_scratch(device) returns that address afterwards (nullptr when it was never resolved).  The

@@ -1,16 +1,34 @@
 // One frame over several GPUs of a node, from one process: the row loop of Camera::render (rendering/camera.rs:58-64)
 // cut into bands that the GPUs take from a shared cursor as they become free (a band costs anything between one ray
 // per pixel in the sky and dozens on glass, so who renders what is decided at run time, not dealt in advance).  The
-// world is small and read-only: every GPU holds its own copy (its own rt_scene).  Built on the public C ABI plus the
-// HIP runtime; RCCL (librccl.so.1, loaded when a second distinct GPU is asked for) moves finished bands into the
-// frame on the first GPU: grouped ncclSend/ncclRecv pairs, each peer's bands over that peer's own xGMI link.
+// world is small and read-only: every GPU holds its own copies (rt_scene handles).  Built on the public C ABI plus the
+// HIP runtime.
+//
+// Workers.  One per entry of `devices`: a host thread that lives as long as the handle (the caller's thread drives
+// worker 0), with two slots -- a stream, a scene handle and two events each -- so that two bands are in flight on its
+// GPU at any time, on two streams: the under-occupied end of one band's launch overlaps the start of the next.
+//
+// Collection of the frame on devices[0].  Workers on that GPU render straight into the frame.  For the others there
+// are two ways, both overlapped with the rendering that is still going on elsewhere:
+//   RT_GATHER_RCCL   a worker that has issued its last band sends its bands with RCCL -- one group of ncclSend /
+//                    ncclRecv pairs, runs of consecutive bands as one message, on a communicator from ncclCommInitAll
+//                    over the distinct GPUs -- over its own xGMI link; the receives run on a stream of devices[0] that
+//                    belongs to that worker.  RCCL is looked for among the libraries already in the process first (a
+//                    host program such as PyTorch brings its own copy; two copies in one process would each set up
+//                    their own transports) and loaded by name otherwise, so the library itself depends on the HIP
+//                    runtime only.
+//   RT_GATHER_COPY   every band is copied by the GPU that rendered it (hipMemcpyPeerAsync on the band's stream, behind
+//                    its kernel): no communicator, no library; used when RCCL is not available, cannot be
+//                    initialised, or RT_MULTI_GATHER=copy is set in the environment.
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -23,25 +41,69 @@
 
 namespace {
 
-// The handful of RCCL entry points used, resolved at run time so that the library itself does not depend on RCCL.
+// The handful of RCCL entry points used, declared here (their C signatures are stable across RCCL 2.x) and resolved at
+// run time, so that neither building nor loading this library needs RCCL.
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;  // ncclSuccess == 0
+enum { kNcclSuccess = 0, kNcclUint8 = 1 /* ncclUint8 == ncclChar + 1 in nccl.h's ncclDataType_t */ };
+
 struct Rccl {
     void *handle = nullptr;
+    bool preloaded = false;  // found in the process already (not loaded by us)
+    std::string path;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
-    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+
+    // A copy of RCCL that the process has mapped already: its path from /proc/self/maps.
+    static std::string mapped_copy() {
+        std::string found;
+        if (FILE *f = std::fopen("/proc/self/maps", "r")) {
+            char line[4096];
+            while (std::fgets(line, sizeof line, f)) {
+                const char *p = std::strstr(line, "librccl.so");
+                if (!p) continue;
+                const char *start = std::strchr(line, '/');
+                if (!start) continue;
+                found.assign(start);
+                while (!found.empty() && (found.back() == '\n' || found.back() == ' ')) found.pop_back();
+                break;
+            }
+            std::fclose(f);
+        }
+        return found;
+    }
 
     bool load(std::string &err) {
         if (handle) return true;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        const std::string mapped = mapped_copy();
+        if (!mapped.empty()) {
+            handle = dlopen(mapped.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            if (handle) {
+                preloaded = true;
+                path = mapped;
+            }
+        }
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
             if (handle) break;
+            handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            if (handle) {
+                preloaded = true;
+                path = name;
+            }
+        }
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (handle) break;
+            handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (handle) path = name;
         }
         if (!handle) {
-            err = std::string("RCCL is needed to collect bands from a second GPU and could not be loaded: ") + dlerror();
+            const char *why = dlerror();
+            err = std::string("RCCL could not be loaded: ") + (why ? why : "librccl.so.1 not found");
             return false;
         }
         auto sym = [&](const char *n) { return dlsym(handle, n); };
@@ -54,27 +116,58 @@ struct Rccl {
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
         if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) {
             err = "librccl lacks one of ncclCommInitAll / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd";
+            handle = nullptr;
             return false;
         }
         return true;
     }
 };
 Rccl g_rccl;
+// One communicator is never used by two threads at a time: every RCCL call of this file is made under this mutex.
 std::mutex g_rccl_mutex;
+
+using Clock = std::chrono::steady_clock;
+double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
+struct Slot {
+    rt_scene *scene = nullptr;      // a handle of its own: handles serve one launch at a time
+    hipStream_t stream = nullptr;
+    hipEvent_t rendered = nullptr;  // behind the band's kernel
+    hipEvent_t done = nullptr;      // behind the band's transfer, if it has one (else behind the kernel)
+    uint32_t band = UINT32_MAX;     // in flight
+};
 
 struct Worker {
     int device = 0;
     int rank = -1;              // index of `device` among the distinct devices (= its rank in the communicator)
     bool on_first = false;      // renders straight into the frame: same GPU as devices[0]
-    rt_scene *scene = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ring[2] = {nullptr, nullptr};
-    char *d_buf = nullptr;      // this GPU's bands, at the offsets they have in the frame (workers not on the first GPU,
-    size_t d_cap = 0;           // and every worker of rt_multi_render)
-    std::vector<uint32_t> mine; // bands taken during the current call
+    Slot slot[2];
+    hipStream_t recv = nullptr;  // on devices[0]: where this worker's bands are received (RCCL collection)
+    char *d_buf = nullptr;       // this GPU's bands, at the offsets they have in the frame (workers not on the first GPU,
+    size_t d_cap = 0;            // and every worker of rt_multi_render)
+    std::vector<uint32_t> mine;  // bands taken during the current call
     rt_stats stats{};
+    double rendered_ms = 0.0, finished_ms = 0.0;  // since the start of the call: last kernel done; last band delivered
     int rc = RT_OK;
     std::string err;
+    std::thread thread;
+};
+
+struct Plan {
+    uint32_t band_rows = 0, n_bands = 0;
+    size_t row_bytes = 0;
+    uint32_t flags = 0;
+    int32_t max_depth = 0;
+    bool stats = false;
+};
+
+struct Job {
+    rt_camera_desc camera{};
+    Plan plan;
+    char *frame_on_first = nullptr;  // where workers on the first GPU render to (nullptr: every worker into its own buffer)
+    char *frame_device = nullptr;    // the frame on devices[0] that bands of other GPUs are collected into (or nullptr)
+    char *stage = nullptr, *rgb = nullptr;  // host frame: pinned staging memory and the caller's buffer
+    Clock::time_point t0;
 };
 
 }  // namespace
@@ -82,10 +175,22 @@ struct Worker {
 struct rt_multi {
     std::vector<Worker> workers;
     std::vector<int> distinct;        // distinct devices, in order of first appearance
-    std::vector<ncclComm_t> comms;    // one per distinct device (empty when there is only one)
+    std::vector<ncclComm_t> comms;    // one per distinct device (empty unless gather == RT_GATHER_RCCL)
+    int gather = RT_GATHER_NONE;
+    std::string gather_note;          // why RCCL is not in use, when it was wanted
     char *h_stage = nullptr;          // pinned staging memory of rt_multi_render, the size of the frame
     size_t h_cap = 0;
     std::vector<uint32_t> last_taken; // bands per worker in the last call
+    std::vector<double> last_ms;      // per worker: when its last kernel had finished, since the start of the call
+    Plan last_plan;
+    // the job the worker threads wait for
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::atomic<uint64_t> generation{0};
+    std::atomic<uint32_t> pending{0};
+    std::atomic<bool> quit{false};
+    Job job;
+    std::atomic<uint32_t> cursor{0};
 };
 
 namespace {
@@ -94,7 +199,8 @@ struct DeviceScope {
     int prev = -1;
     explicit DeviceScope(int device) {
         (void)hipGetDevice(&prev);
-        (void)hipSetDevice(device);
+        if (prev != device) (void)hipSetDevice(device);
+        else prev = -1;
     }
     ~DeviceScope() {
         if (prev >= 0) (void)hipSetDevice(prev);
@@ -120,13 +226,19 @@ void add_stats(rt_stats &into, const rt_stats &s) {
     into.specular += s.specular; into.patterns += s.patterns; into.refract_setups += s.refract_setups; into.schlick += s.schlick;
 }
 
-struct Plan {
-    uint32_t band_rows = 0, n_bands = 0;
-    size_t row_bytes = 0;
-    uint32_t flags = 0;
-    int32_t max_depth = 0;
-    bool stats = false;
-};
+// Height of a band when the caller names none.  A launch fills the GPU with 4 096 waves of one 8x8-pixel tile each and
+// ends with a tail of its slowest tiles, so a band should be a few such generations; more bands than workers let a GPU
+// that drew cheap rows take another.  Aim at four bands per worker, but never fewer than 8 192 tiles per band; one
+// worker alone takes the frame as one band (exactly what rt_render_device does).
+uint32_t default_band_rows(const rt_camera_desc &camera, size_t n_workers) {
+    const uint32_t whole = (camera.vsize + 7u) / 8u * 8u;
+    if (n_workers <= 1) return whole;
+    const uint64_t tiles_x = (camera.hsize + 7u) / 8u;
+    const uint64_t tiles = tiles_x * ((camera.vsize + 7u) / 8u);
+    const uint64_t per_band = std::max<uint64_t>(8192u, tiles / (4u * n_workers));
+    const uint64_t tile_rows = std::max<uint64_t>(1u, (per_band + tiles_x - 1u) / tiles_x);
+    return (uint32_t)std::min<uint64_t>(whole, tile_rows * 8u);
+}
 
 // Validates a multi-GPU render call and cuts the frame into bands.
 int make_plan(const rt_multi *m, const rt_camera_desc *camera, const rt_render_opts *opts, bool device_frame, Plan &plan) {
@@ -143,56 +255,95 @@ int make_plan(const rt_multi *m, const rt_camera_desc *camera, const rt_render_o
         plan.stats = opts->collect_stats != 0;
         plan.band_rows = opts->band_rows;
     }
-    if (plan.band_rows == 0) {
-        // about four bands per worker, so that a slow band can be made up for; never less than 64 rows (a launch
-        // needs thousands of 8x8 tiles to fill a GPU), always whole tiles
-        uint32_t rows = camera->vsize / (4u * (uint32_t)m->workers.size());
-        rows = std::max(64u, (rows + 7u) / 8u * 8u);
-        plan.band_rows = std::min(rows, (camera->vsize + 7u) / 8u * 8u);
-    }
+    if (plan.band_rows == 0) plan.band_rows = default_band_rows(*camera, m->workers.size());
     plan.n_bands = (camera->vsize + plan.band_rows - 1) / plan.band_rows;
     plan.row_bytes = (size_t)camera->hsize * 3 * ((plan.flags & RT_RENDER_QUANTIZED) ? 1 : sizeof(double));
     return RT_OK;
 }
 
+void worker_failed(Worker &w, int rc, const std::string &what) {
+    if (w.rc != RT_OK) return;
+    w.rc = rc;
+    w.err = what;
+}
+
+// RCCL collection of one worker's bands into the frame on devices[0]: runs of consecutive bands as one message, all of
+// them in one group; the sends wait for both of the worker's streams, the receives run on the worker's stream on
+// devices[0].  Called by the worker's thread once it has issued its last band; returns when the bands have arrived.
+void collect_with_rccl(rt_multi *m, Worker &w, const Job &job, size_t frame_bytes) {
+    if (w.mine.empty()) return;
+    hipError_t e = hipStreamWaitEvent(w.slot[0].stream, w.slot[1].rendered, 0);  // (an event never recorded counts as complete)
+    if (e != hipSuccess) return worker_failed(w, RT_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
+    std::vector<uint32_t> bands = w.mine;
+    std::sort(bands.begin(), bands.end());
+    const Plan &plan = job.plan;
+    const int first_rank = m->workers[0].rank;
+    ncclResult_t r;
+    {
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        r = g_rccl.GroupStart();
+        for (size_t k = 0; k < bands.size() && r == kNcclSuccess;) {
+            size_t j = k + 1;
+            while (j < bands.size() && bands[j] == bands[j - 1] + 1) ++j;
+            const size_t off = (size_t)bands[k] * plan.band_rows * plan.row_bytes;
+            const size_t end = std::min<size_t>(frame_bytes, (size_t)(bands[j - 1] + 1) * plan.band_rows * plan.row_bytes);
+            r = g_rccl.Send(w.d_buf + off, end - off, kNcclUint8, first_rank, m->comms[(size_t)w.rank], w.slot[0].stream);
+            if (r == kNcclSuccess) r = g_rccl.Recv(job.frame_device + off, end - off, kNcclUint8, w.rank, m->comms[(size_t)first_rank], w.recv);
+            k = j;
+        }
+        const ncclResult_t r_end = g_rccl.GroupEnd();
+        if (r == kNcclSuccess) r = r_end;
+    }
+    if (r != kNcclSuccess) return worker_failed(w, RT_ERR_HIP, std::string("collecting the bands with RCCL: ") + g_rccl.GetErrorString(r));
+    e = hipStreamSynchronize(w.slot[0].stream);
+    if (e == hipSuccess) {
+        DeviceScope first(m->workers[0].device);
+        e = hipStreamSynchronize(w.recv);
+    }
+    if (e != hipSuccess) worker_failed(w, RT_ERR_HIP, std::string("waiting for the collected bands: ") + hipGetErrorString(e));
+}
+
 // One worker's part of a call: takes bands from the cursor while its GPU has fewer than two in flight.
-// `frame_on_first`: where workers on the first GPU render to (nullptr: every worker renders into its own buffer);
-// `stage` / `rgb`: when set, every band is copied to pinned staging memory behind its kernel and from there into the
-// caller's frame by this thread.
-void run_worker(Worker &w, const rt_camera_desc &camera, const Plan &plan, std::atomic<uint32_t> &cursor, char *frame_on_first,
-                char *stage, char *rgb) {
+void run_worker(rt_multi *m, Worker &w) {
+    const Job &job = m->job;
+    const Plan &plan = job.plan;
+    const rt_camera_desc &camera = job.camera;
     w.mine.clear();
     std::memset(&w.stats, 0, sizeof w.stats);
     w.rc = RT_OK;
-    if (hipSetDevice(w.device) != hipSuccess) {
-        w.rc = RT_ERR_HIP;
-        w.err = "hipSetDevice failed";
-        return;
-    }
-    char *base = (frame_on_first && w.on_first) ? frame_on_first : w.d_buf;
-    uint32_t in_flight[2] = {UINT32_MAX, UINT32_MAX};
+    w.err.clear();
+    w.rendered_ms = w.finished_ms = 0.0;
+    w.slot[0].band = w.slot[1].band = UINT32_MAX;
+    if (hipSetDevice(w.device) != hipSuccess) return worker_failed(w, RT_ERR_HIP, "hipSetDevice failed");
+    const size_t frame_bytes = (size_t)camera.vsize * plan.row_bytes;
+    const bool straight = job.frame_on_first && w.on_first;     // renders into the frame itself
+    const bool collect = job.frame_device && !w.on_first;       // its bands travel to devices[0]
+    char *base = straight ? job.frame_on_first : w.d_buf;
     auto band_bytes = [&](uint32_t b) {
         const uint32_t y0 = b * plan.band_rows, y1 = std::min(camera.vsize, y0 + plan.band_rows);
         return (size_t)(y1 - y0) * plan.row_bytes;
     };
-    auto retire = [&](int slot) {  // waits for the band issued into `slot` and delivers it
-        if (in_flight[slot] == UINT32_MAX) return true;
-        const hipError_t e = hipEventSynchronize(w.ring[slot]);
+    if (plan.stats)
+        for (Slot &s : w.slot)
+            if (rt::capi_counters_reset(s.scene, s.stream) != RT_OK) return worker_failed(w, RT_ERR_HIP, rt_last_error());
+    auto retire = [&](Slot &s) {  // waits for the band in flight in `s` and delivers it
+        if (s.band == UINT32_MAX) return true;
+        const hipError_t e = hipEventSynchronize(s.done);
         if (e != hipSuccess) {
-            w.rc = RT_ERR_HIP;
-            w.err = std::string("hipEventSynchronize: ") + hipGetErrorString(e);
+            worker_failed(w, RT_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
             return false;
         }
-        if (rgb) {
-            const size_t off = (size_t)in_flight[slot] * plan.band_rows * plan.row_bytes;
-            std::memcpy(rgb + off, stage + off, band_bytes(in_flight[slot]));
+        if (job.rgb) {
+            const size_t off = (size_t)s.band * plan.band_rows * plan.row_bytes;
+            std::memcpy(job.rgb + off, job.stage + off, band_bytes(s.band));
         }
-        in_flight[slot] = UINT32_MAX;
+        s.band = UINT32_MAX;
         return true;
     };
-    for (int slot = 0;; slot ^= 1) {
-        if (!retire(slot)) break;
-        const uint32_t b = cursor.fetch_add(1);
+    for (int k = 0;; k ^= 1) {
+        Slot &s = w.slot[k];
+        if (!retire(s)) break;
+        const uint32_t b = m->cursor.fetch_add(1);
         if (b >= plan.n_bands) break;
         rt_render_opts o;
         std::memset(&o, 0, sizeof o);
@@ -200,59 +351,127 @@ void run_worker(Worker &w, const rt_camera_desc &camera, const Plan &plan, std::
         o.row_end = std::min(camera.vsize, o.row_begin + plan.band_rows);
         o.max_depth = plan.max_depth;
         o.flags = plan.flags;
-        o.collect_stats = plan.stats ? 1 : 0;
-        o.stream = w.stream;
+        o.stream = s.stream;
         const size_t off = (size_t)o.row_begin * plan.row_bytes;
-        rt_stats st;
-        int rc = rt_render_device(w.scene, &camera, &o, reinterpret_cast<double *>(base + off), plan.stats ? &st : nullptr);
+        double *target = reinterpret_cast<double *>(base + off);
+        const int rc = plan.stats ? rt::capi_render_device_counting(s.scene, &camera, &o, target) : rt_render_device(s.scene, &camera, &o, target, nullptr);
         if (rc != RT_OK) {
-            w.rc = rc;
-            w.err = rt_last_error();
+            worker_failed(w, rc, rt_last_error());
             break;
         }
-        if (plan.stats) add_stats(w.stats, st);
-        hipError_t e = hipSuccess;
-        if (stage) e = hipMemcpyAsync(stage + off, base + off, band_bytes(b), hipMemcpyDeviceToHost, w.stream);
-        if (e == hipSuccess) e = hipEventRecord(w.ring[slot], w.stream);
+        hipError_t e = hipEventRecord(s.rendered, s.stream);
+        if (e == hipSuccess && job.stage) e = hipMemcpyAsync(job.stage + off, base + off, band_bytes(b), hipMemcpyDeviceToHost, s.stream);
+        else if (e == hipSuccess && collect && m->gather == RT_GATHER_COPY)
+            e = hipMemcpyPeerAsync(job.frame_device + off, m->workers[0].device, base + off, w.device, band_bytes(b), s.stream);
+        if (e == hipSuccess) e = hipEventRecord(s.done, s.stream);
         if (e != hipSuccess) {
-            w.rc = RT_ERR_HIP;
-            w.err = std::string("queueing a band: ") + hipGetErrorString(e);
+            worker_failed(w, RT_ERR_HIP, std::string("queueing a band: ") + hipGetErrorString(e));
             break;
         }
-        in_flight[slot] = b;
+        s.band = b;
         w.mine.push_back(b);
     }
-    (void)retire(0);
-    (void)retire(1);
-    if (hipStreamSynchronize(w.stream) != hipSuccess && w.rc == RT_OK) {
-        w.rc = RT_ERR_HIP;
-        w.err = "hipStreamSynchronize failed";
+    // the kernels of this GPU have finished when both slots' `rendered` events have
+    for (Slot &s : w.slot)
+        if (s.band != UINT32_MAX && hipEventSynchronize(s.rendered) != hipSuccess) worker_failed(w, RT_ERR_HIP, "hipEventSynchronize failed");
+    w.rendered_ms = ms_since(job.t0);
+    if (w.rc == RT_OK && collect && m->gather == RT_GATHER_RCCL) collect_with_rccl(m, w, job, frame_bytes);
+    (void)retire(w.slot[0]);
+    (void)retire(w.slot[1]);
+    for (Slot &s : w.slot)
+        if (hipStreamSynchronize(s.stream) != hipSuccess) worker_failed(w, RT_ERR_HIP, "hipStreamSynchronize failed");
+    if (plan.stats && w.rc == RT_OK)
+        for (Slot &s : w.slot) {
+            rt_stats st;
+            if (rt::capi_counters_read(s.scene, s.stream, &st) != RT_OK) worker_failed(w, RT_ERR_HIP, rt_last_error());
+            else add_stats(w.stats, st);
+        }
+    w.finished_ms = ms_since(job.t0);
+}
+
+// A worker thread: waits for the next job (spinning for a short while first: in a frame loop the next job is a few
+// microseconds away, and waking from a condition variable costs more than a small frame's band), runs its part, reports.
+void worker_main(rt_multi *m, size_t k) {
+    uint64_t seen = 0;
+    (void)hipSetDevice(m->workers[k].device);
+    for (;;) {
+        const Clock::time_point idle_since = Clock::now();
+        while (m->generation.load(std::memory_order_acquire) == seen && !m->quit.load(std::memory_order_acquire)) {
+            if (ms_since(idle_since) < 0.3) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+                continue;
+            }
+            std::unique_lock<std::mutex> lock(m->mu);
+            m->cv_go.wait(lock, [&] { return m->generation.load(std::memory_order_acquire) != seen || m->quit.load(std::memory_order_acquire); });
+        }
+        if (m->quit.load(std::memory_order_acquire)) return;
+        seen = m->generation.load(std::memory_order_acquire);
+        run_worker(m, m->workers[k]);
+        if (m->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            std::lock_guard<std::mutex> lock(m->mu);
+            m->cv_done.notify_all();
+        }
     }
 }
 
-int run_all(rt_multi *m, const rt_camera_desc &camera, const Plan &plan, char *frame_on_first, char *stage, char *rgb, rt_stats *stats,
-            double *wall_ms) {
-    std::atomic<uint32_t> cursor{0};
-    const auto t0 = std::chrono::steady_clock::now();
-    std::vector<std::thread> threads;
-    for (size_t k = 1; k < m->workers.size(); ++k)
-        threads.emplace_back([&, k] { run_worker(m->workers[k], camera, plan, cursor, frame_on_first, stage, rgb); });
+int run_all(rt_multi *m, rt_stats *stats) {
+    m->cursor.store(0);
+    m->job.t0 = Clock::now();
+    const uint32_t others = (uint32_t)m->workers.size() - 1;
+    if (others) {
+        std::lock_guard<std::mutex> lock(m->mu);
+        m->pending.store(others, std::memory_order_release);
+        m->generation.fetch_add(1, std::memory_order_acq_rel);
+        m->cv_go.notify_all();
+    }
     {
         int prev = -1;
         (void)hipGetDevice(&prev);
-        run_worker(m->workers[0], camera, plan, cursor, frame_on_first, stage, rgb);  // the caller's thread drives the first GPU
+        run_worker(m, m->workers[0]);  // the caller's thread drives the first worker
         if (prev >= 0) (void)hipSetDevice(prev);
     }
-    for (std::thread &t : threads) t.join();
-    *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (others) {
+        const Clock::time_point waiting_since = Clock::now();
+        while (m->pending.load(std::memory_order_acquire) != 0) {
+            if (ms_since(waiting_since) < 0.3) continue;
+            std::unique_lock<std::mutex> lock(m->mu);
+            m->cv_done.wait(lock, [&] { return m->pending.load(std::memory_order_acquire) == 0; });
+        }
+    }
+    m->last_plan = m->job.plan;
     m->last_taken.assign(m->workers.size(), 0);
+    m->last_ms.assign(m->workers.size(), 0.0);
+    double rendered = 0.0, finished = 0.0;
     for (size_t k = 0; k < m->workers.size(); ++k) {
         const Worker &w = m->workers[k];
         if (w.rc != RT_OK) return rt::capi_set_error(w.rc, "GPU " + std::to_string(w.device) + ": " + w.err);
         m->last_taken[k] = (uint32_t)w.mine.size();
-        if (stats && plan.stats) add_stats(*stats, w.stats);
+        m->last_ms[k] = w.rendered_ms;
+        rendered = std::max(rendered, w.rendered_ms);
+        finished = std::max(finished, w.finished_ms);
+        if (stats && m->job.plan.stats) add_stats(*stats, w.stats);
+    }
+    if (stats) {
+        stats->kernel_ms = rendered;
+        stats->gather_ms = std::max(0.0, finished - rendered);
     }
     return RT_OK;
+}
+
+// Lets every other GPU of the handle reach memory of devices[0] (and the reverse, which RCCL's transports want):
+// peer copies then go over xGMI directly instead of through host memory.  Failing here costs speed, not correctness.
+void enable_peer_access(const std::vector<int> &distinct) {
+    for (size_t a = 0; a < distinct.size(); ++a)
+        for (size_t b = 0; b < distinct.size(); ++b) {
+            if (a == b || (a != 0 && b != 0)) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, distinct[a], distinct[b]) != hipSuccess || !can) continue;
+            DeviceScope scope(distinct[a]);
+            const hipError_t e = hipDeviceEnablePeerAccess(distinct[b], 0);
+            if (e != hipSuccess) (void)hipGetLastError();  // hipErrorPeerAccessAlreadyEnabled included: clear the sticky error
+        }
 }
 
 }  // namespace
@@ -280,43 +499,97 @@ int rt_multi_create(const rt_world_desc *world, const int *devices, uint32_t n_d
         }
         w.rank = (int)(it - m->distinct.begin());
         w.on_first = w.device == devices[0];
-        int rc = rt_scene_create(world, w.device, &w.scene);  // a handle of its own per worker: handles serve one call at a time
-        if (rc != RT_OK) return rc;
-        DeviceScope scope(w.device);
-        e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking);
-        for (int s = 0; e == hipSuccess && s < 2; ++s) e = hipEventCreateWithFlags(&w.ring[s], hipEventDisableTiming);
-        if (e != hipSuccess) return fail_hip(e, "creating a worker's stream and events");
-    }
-    if (m->distinct.size() > 1) {
-        std::lock_guard<std::mutex> lock(g_rccl_mutex);
-        std::string err;
-        if (!g_rccl.load(err)) return rt::capi_set_error(RT_ERR_UNSUPPORTED, err);
-        m->comms.assign(m->distinct.size(), nullptr);
-        const ncclResult_t r = g_rccl.CommInitAll(m->comms.data(), (int)m->distinct.size(), m->distinct.data());
-        if (r != ncclSuccess) {
-            m->comms.clear();
-            return rt::capi_set_error(RT_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+        for (Slot &s : w.slot) {
+            int rc = rt_scene_create(world, w.device, &s.scene);
+            if (rc != RT_OK) return rc;
+            DeviceScope scope(w.device);
+            e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.rendered, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+            if (e != hipSuccess) return fail_hip(e, "creating a worker's streams and events");
+        }
+        if (!w.on_first) {
+            DeviceScope scope(devices[0]);
+            e = hipStreamCreateWithFlags(&w.recv, hipStreamNonBlocking);
+            if (e != hipSuccess) return fail_hip(e, "creating a worker's receiving stream");
         }
     }
+    if (m->distinct.size() > 1) {
+        enable_peer_access(m->distinct);
+        m->gather = RT_GATHER_COPY;
+        const char *want = getenv("RT_MULTI_GATHER");
+        if (want && std::strcmp(want, "copy") == 0) {
+            m->gather_note = "RT_MULTI_GATHER=copy";
+        } else {
+            std::lock_guard<std::mutex> lock(g_rccl_mutex);
+            std::string err;
+            if (!g_rccl.load(err)) {
+                m->gather_note = err;
+            } else {
+                m->comms.assign(m->distinct.size(), nullptr);
+                const ncclResult_t r = g_rccl.CommInitAll(m->comms.data(), (int)m->distinct.size(), m->distinct.data());
+                if (r != kNcclSuccess) {
+                    m->comms.clear();
+                    m->gather_note = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r);
+                } else {
+                    m->gather = RT_GATHER_RCCL;
+                }
+            }
+            if (m->gather != RT_GATHER_RCCL && want && std::strcmp(want, "rccl") == 0)  // asked for by name: no silent fallback
+                return rt::capi_set_error(RT_ERR_UNSUPPORTED, "RT_MULTI_GATHER=rccl: " + m->gather_note);
+        }
+    }
+    for (size_t k = 1; k < m->workers.size(); ++k) m->workers[k].thread = std::thread(worker_main, m.get(), k);
     *out = m.release();
     return RT_OK;
 }
 
 void rt_multi_destroy(rt_multi *m) {
     if (!m) return;
-    for (ncclComm_t c : m->comms)
-        if (c) (void)g_rccl.CommDestroy(c);
+    {
+        std::lock_guard<std::mutex> lock(m->mu);
+        m->quit.store(true, std::memory_order_release);
+        m->cv_go.notify_all();
+    }
+    for (Worker &w : m->workers)
+        if (w.thread.joinable()) w.thread.join();
+    if (!m->comms.empty()) {
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        for (size_t r = 0; r < m->comms.size(); ++r)
+            if (m->comms[r]) {
+                DeviceScope scope(m->distinct[r]);
+                (void)g_rccl.CommDestroy(m->comms[r]);
+            }
+    }
     for (Worker &w : m->workers) {
-        if (!w.scene && !w.stream && !w.d_buf) continue;  // never set up
+        if (w.recv) {
+            DeviceScope scope(m->workers[0].device);
+            (void)hipStreamDestroy(w.recv);
+        }
         DeviceScope scope(w.device);
         if (w.d_buf) (void)hipFree(w.d_buf);
-        for (hipEvent_t ev : w.ring)
-            if (ev) (void)hipEventDestroy(ev);
-        if (w.stream) (void)hipStreamDestroy(w.stream);
-        if (w.scene) rt_scene_destroy(w.scene);
+        for (Slot &s : w.slot) {
+            if (s.rendered) (void)hipEventDestroy(s.rendered);
+            if (s.done) (void)hipEventDestroy(s.done);
+            if (s.stream) (void)hipStreamDestroy(s.stream);
+            if (s.scene) rt_scene_destroy(s.scene);
+        }
     }
     if (m->h_stage) (void)hipHostFree(m->h_stage);
     delete m;
+}
+
+int rt_multi_get_info(const rt_multi *m, rt_multi_info *out) {
+    if (!m || !out) return rt::capi_set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::memset(out, 0, sizeof *out);
+    out->n_workers = (uint32_t)m->workers.size();
+    out->n_devices = (uint32_t)m->distinct.size();
+    out->gather = m->gather;
+    out->rccl_ranks = (uint32_t)m->comms.size();
+    out->band_rows = m->last_plan.band_rows;
+    out->n_bands = m->last_plan.n_bands;
+    std::snprintf(out->note, sizeof out->note, "%s", m->gather == RT_GATHER_RCCL ? g_rccl.path.c_str() : m->gather_note.c_str());
+    return RT_OK;
 }
 
 int rt_multi_render_device(rt_multi *m, const rt_camera_desc *camera, const rt_render_opts *opts, void *frame_device, rt_stats *stats) {
@@ -333,41 +606,12 @@ int rt_multi_render_device(rt_multi *m, const rt_camera_desc *camera, const rt_r
             hipError_t e = grow_device(w, frame_bytes);
             if (e != hipSuccess) return fail_hip(e, "allocating a GPU's band buffer");
         }
-    double wall_ms = 0.0;
-    rc = run_all(m, *camera, plan, static_cast<char *>(frame_device), nullptr, nullptr, stats, &wall_ms);
-    if (rc != RT_OK) return rc;
-    // The bands rendered on other GPUs travel to the frame: runs of consecutive bands of one worker as one message,
-    // all messages of the call in one group so that every peer's link is busy at the same time.
-    if (!m->comms.empty()) {
-        Worker &first = m->workers[0];
-        bool any = false;
-        ncclResult_t r = g_rccl.GroupStart();
-        for (Worker &w : m->workers) {
-            if (w.on_first || r != ncclSuccess) continue;
-            std::sort(w.mine.begin(), w.mine.end());
-            for (size_t k = 0; k < w.mine.size() && r == ncclSuccess;) {
-                size_t j = k + 1;
-                while (j < w.mine.size() && w.mine[j] == w.mine[j - 1] + 1) ++j;
-                const size_t off = (size_t)w.mine[k] * plan.band_rows * plan.row_bytes;
-                const size_t end = std::min<size_t>(frame_bytes, (size_t)(w.mine[j - 1] + 1) * plan.band_rows * plan.row_bytes);
-                r = g_rccl.Send(w.d_buf + off, end - off, ncclUint8, first.rank, m->comms[(size_t)w.rank], w.stream);
-                if (r == ncclSuccess) r = g_rccl.Recv(static_cast<char *>(frame_device) + off, end - off, ncclUint8, w.rank, m->comms[(size_t)first.rank], first.stream);
-                any = true;
-                k = j;
-            }
-        }
-        const ncclResult_t r_end = g_rccl.GroupEnd();
-        if (r == ncclSuccess) r = r_end;
-        if (r != ncclSuccess) return rt::capi_set_error(RT_ERR_HIP, std::string("collecting the bands with RCCL: ") + g_rccl.GetErrorString(r));
-        if (any)
-            for (Worker &w : m->workers) {
-                DeviceScope scope(w.device);
-                hipError_t e = hipStreamSynchronize(w.stream);
-                if (e != hipSuccess) return fail_hip(e, "waiting for the collected bands");
-            }
-    }
-    if (stats) stats->kernel_ms = wall_ms;
-    return RT_OK;
+    m->job = Job{};
+    m->job.camera = *camera;
+    m->job.plan = plan;
+    m->job.frame_on_first = static_cast<char *>(frame_device);
+    m->job.frame_device = static_cast<char *>(frame_device);
+    return run_all(m, stats);
 }
 
 int rt_multi_render(rt_multi *m, const rt_camera_desc *camera, const rt_render_opts *opts, double *rgb, rt_stats *stats) {
@@ -392,16 +636,23 @@ int rt_multi_render(rt_multi *m, const rt_camera_desc *camera, const rt_render_o
         if (e != hipSuccess) return fail_hip(e, "allocating pinned staging memory");
         m->h_cap = frame_bytes;
     }
-    double wall_ms = 0.0;
-    rc = run_all(m, *camera, plan, nullptr, m->h_stage, reinterpret_cast<char *>(rgb), stats, &wall_ms);
-    if (rc != RT_OK) return rc;
-    if (stats) stats->kernel_ms = wall_ms;
-    return RT_OK;
+    m->job = Job{};
+    m->job.camera = *camera;
+    m->job.plan = plan;
+    m->job.stage = m->h_stage;
+    m->job.rgb = reinterpret_cast<char *>(rgb);
+    return run_all(m, stats);
 }
 
 int rt_multi_bands_taken(const rt_multi *m, uint32_t *per_worker, uint32_t n) {
     if (!m || (!per_worker && n)) return rt::capi_set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
     for (uint32_t k = 0; k < n; ++k) per_worker[k] = k < m->last_taken.size() ? m->last_taken[k] : 0u;
+    return RT_OK;
+}
+
+int rt_multi_worker_ms(const rt_multi *m, double *per_worker, uint32_t n) {
+    if (!m || (!per_worker && n)) return rt::capi_set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    for (uint32_t k = 0; k < n; ++k) per_worker[k] = k < m->last_ms.size() ? m->last_ms[k] : 0.0;
     return RT_OK;
 }
 

@@ -1,0 +1,187 @@
+"""One frame over several workers / several GPUs through the C ABI's rt_multi_* entry points, at the benchmark's
+frame sizes, and bench.py's single-process several-GPU path (all tests need an MI355X).
+
+A test box has ONE GPU: several workers are then several host threads, streams and scene handles on that GPU (device 0
+listed more than once), which exercises everything but the transfer between GPUs.  The tests at the end of the file run
+only where a second GPU is visible and compare a frame assembled across two GPUs, by either way of collecting it, with
+the single-GPU frame bit for bit."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, scene_path
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(GOLDEN))
+
+
+def _hip():
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    return hip
+
+
+def _device_frame(hip, buf, nbytes, dtype, shape):
+    got = np.zeros(nbytes, dtype=np.uint8)
+    assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), buf, nbytes, 2) == 0
+    return got.view(dtype).reshape(shape)
+
+
+def _plain_env():
+    """The environment without a launcher's variables: bench.py must take its single-process path."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RT_BENCH_FORCE_DIST", "RT_BENCH_BACKEND"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_drives_several_workers_without_a_launcher(gpu):
+    """`python bench.py --gpus 2` started plainly: one process, rt_multi_render_device, two workers (here both on GPU 0 via
+    RT_BENCH_DEVICES), the collected frame equal to the single-GPU frame (`--check`, exit status 3 otherwise)."""
+    env = dict(_plain_env(), RT_BENCH_DEVICES="0,0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--check",
+           "--no-cpu-baseline", "--width", "1920", "--height", "1080"]
+    done = subprocess.run(cmd, capture_output=True, text=True, timeout=170, env=env, cwd=ROOT)
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert "collected frame equals the single-GPU frame" in done.stderr
+    line = json.loads(done.stdout.strip().splitlines()[-1])
+    assert line["workers"] == 2 and line["n_gpus"] == 1 and line["devices"] == [0, 0]
+    assert line["config"]["path"] == "single process, rt_multi_render_device"
+    assert line["gather"] == "none" and line["rccl_ranks"] == 0
+    assert sum(line["bands_taken"]) == line["bands"] >= 2 and len(line["bands_taken"]) == 2
+    assert line["value"] > 0 and line["config"]["rays_per_frame"] > 1920 * 1080 and line["gather_ms"] >= 0.0
+    assert line["render_ms"] > 0.0 and len(line["worker_render_ms"]) == 2
+
+
+def test_bench_refuses_more_gpus_than_there_are(gpu):
+    """--gpus N with fewer than N GPUs visible is an error (status 4), not a silent one-GPU run."""
+    n = gpu + 1  # the fixture's value: HIP devices visible to this process
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+           "--width", "64", "--height", "64"]
+    done = subprocess.run(cmd, capture_output=True, text=True, timeout=170, env=_plain_env(), cwd=ROOT)
+    assert done.returncode == 4 and "GPU(s) visible" in done.stderr, (done.returncode, done.stderr[-1000:])
+
+
+@pytest.mark.parametrize("name", ["chapter_11", "chapter_14"])
+def test_several_workers_at_the_benchmark_frame_size(gpu, rt, orc, name):
+    """3840x2160, where band count, the two-bands-in-flight ring and 199 MB of pinned staging matter: two workers (and
+    three with a band height of its own) against the single-device frame, bit for bit -- in device memory as f64 and as
+    8-bit values, and in host memory; counters add up."""
+    hip = _hip()
+    w, h = 3840, 2160
+    sf = rt.SceneFile.from_file(scene_path(name))
+    cam, world = sf.build_camera(w, h), sf.build_world()
+    scene = world.scene()
+    full, st_full = scene.render(cam, stats=True)
+    q_full = orc.quantize(full)
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), full.nbytes + 64) == 0
+    try:
+        for devices, band_rows in (([0, 0], 0), ([0, 0, 0], 200), ([0], 0)):
+            multi = world.multi_scene(devices)
+            assert hip.hipMemset(buf, 0xA5, full.nbytes + 64) == 0
+            st = multi.render_device(cam, buf.value, band_rows=band_rows, stats=True)
+            got = _device_frame(hip, buf, full.nbytes + 64, np.uint8, (-1,))
+            assert np.array_equal(got[:full.nbytes].view(np.float64).reshape(full.shape), full), (devices, band_rows)
+            assert (got[full.nbytes:] == 0xA5).all(), "wrote past the frame"
+            assert st.as_dict() == st_full.as_dict()
+            info = multi.info()
+            assert sum(multi.bands_taken()) == info["n_bands"]
+            if len(devices) == 2:  # the default plan: bands of at least 8 192 tiles, about four per worker
+                assert info["band_rows"] % 8 == 0 and info["band_rows"] // 8 * 480 >= 8192 and 4 <= info["n_bands"] <= 8
+            if len(devices) == 1:
+                assert info["n_bands"] == 1
+            multi.render_device(cam, buf.value, band_rows=band_rows, quantized=True)
+            assert np.array_equal(_device_frame(hip, buf, w * h * 3, np.uint8, (h, w, 3)), q_full)
+            host, st = multi.render(cam, band_rows=band_rows)
+            assert np.array_equal(host, full)
+            del host
+            multi.close()
+    finally:
+        hip.hipFree(buf)
+
+
+def test_one_worker_costs_what_the_single_device_call_costs(gpu, rt):
+    """rt_multi_render_device with devices = [0] is rt_render_device plus a wait for completion: on the benchmark frame
+    it must stay within a few per cent of it (generous bound here; bench.py reports the figure as multi_single_gpu_ms)."""
+    hip = _hip()
+    sf = rt.SceneFile.from_file(scene_path("chapter_11"))
+    cam, world = sf.build_camera(3840, 2160), sf.build_world()
+    scene, multi = world.scene(), world.multi_scene([0])
+    frame = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(frame), 3840 * 2160 * 3) == 0
+
+    def single():
+        scene.render_device(cam, frame.value, None, None, 0, False, False, True)
+        assert hip.hipDeviceSynchronize() == 0
+
+    def several():
+        multi.render_device(cam, frame.value, quantized=True)
+
+    try:
+        for _ in range(40):
+            single()
+            several()
+        times = {}
+        for label, fn in (("single", single), ("multi", several), ("single2", single), ("multi2", several)):
+            t0 = time.perf_counter()
+            for _ in range(30):
+                fn()
+            times[label] = (time.perf_counter() - t0) / 30
+        a, b = min(times["single"], times["single2"]), min(times["multi"], times["multi2"])
+        assert b <= 1.10 * a, times
+    finally:
+        multi.close()
+        hip.hipFree(frame)
+
+
+# --------------------------------------------------------------------------- two GPUs (skipped on a one-GPU box)
+@pytest.mark.parametrize("gather", ["rccl", "copy"])
+def test_frame_assembled_across_two_gpus(gpu, rt, orc, gather, monkeypatch):
+    """Bands rendered on GPU 1 travel to the frame on GPU 0 -- with RCCL (grouped ncclSend / ncclRecv) and with peer
+    copies -- and the frame is the single-GPU frame bit for bit.  Needs two GPUs."""
+    if gpu < 2:
+        pytest.skip("needs a second GPU")
+    hip = _hip()
+    monkeypatch.setenv("RT_MULTI_GATHER", gather)
+    for name, (w, h) in (("chapter_11", (1920, 1080)), ("chapter_14", (1280, 720))):
+        sf = rt.SceneFile.from_file(scene_path(name))
+        cam, world = sf.build_camera(w, h), sf.build_world()
+        full, st_full = world.scene(0).render(cam, stats=True)
+        buf = ctypes.c_void_p()
+        assert hip.hipSetDevice(0) == 0
+        assert hip.hipMalloc(ctypes.byref(buf), full.nbytes) == 0
+        try:
+            for devices, band_rows in (([0, 1], 0), ([0, 1, 1], 64), ([1, 0], 128)):
+                multi = world.multi_scene(devices)
+                info = multi.info()
+                assert info["gather"] == gather and info["n_devices"] == 2 and info["rccl_ranks"] == (2 if gather == "rccl" else 0)
+                assert hip.hipSetDevice(devices[0]) == 0
+                frame = ctypes.c_void_p()
+                assert hip.hipMalloc(ctypes.byref(frame), full.nbytes) == 0
+                for quantized in (False, True):
+                    assert hip.hipMemset(frame, 0xA5, full.nbytes) == 0
+                    st = multi.render_device(cam, frame.value, band_rows=band_rows, stats=not quantized, quantized=quantized)
+                    if quantized:
+                        assert np.array_equal(_device_frame(hip, frame, w * h * 3, np.uint8, (h, w, 3)), orc.quantize(full))
+                    else:
+                        assert np.array_equal(_device_frame(hip, frame, full.nbytes, np.float64, full.shape), full), (name, devices)
+                        assert st.as_dict() == st_full.as_dict()
+                    assert sum(multi.bands_taken()) == multi.info()["n_bands"]
+                host, _ = multi.render(cam, band_rows=band_rows)
+                assert np.array_equal(host, full)
+                hip.hipFree(frame)
+                multi.close()
+        finally:
+            hip.hipSetDevice(0)
+            hip.hipFree(buf)

@@ -1017,7 +1017,6 @@ def test_several_workers_share_one_frame(gpu, rt, orc):
         try:
             for devices, band_rows in (([0, 0], 0), ([0, 0, 0], 8), ([0], 24), ([0, 0], 1000)):
                 multi = world.multi_scene(devices)
-                n_bands = (h + (band_rows or 64) - 1) // (band_rows or 64)
                 # frame in device memory, f64
                 assert hip.hipMemset(buf, 0xA5, full.nbytes + 64) == 0
                 st = multi.render_device(cam, buf.value, band_rows=band_rows, stats=True)
@@ -1026,7 +1025,12 @@ def test_several_workers_share_one_frame(gpu, rt, orc):
                 assert np.array_equal(got[:full.nbytes].view(np.float64).reshape(full.shape), full), (name, devices, band_rows)
                 assert (got[full.nbytes:] == 0xA5).all(), "wrote past the frame"
                 assert st.as_dict() == st_full.as_dict()
-                assert sum(multi.bands_taken()) == n_bands and len(multi.bands_taken()) == len(devices)
+                info = multi.info()
+                # no band height named: one worker takes the frame whole, several cut it -- but not below 8 192 tiles a band
+                assert info["band_rows"] == (band_rows or (h + 7) // 8 * 8) and info["n_bands"] == (h + info["band_rows"] - 1) // info["band_rows"]
+                assert (info["n_workers"], info["n_devices"], info["gather"], info["rccl_ranks"]) == (len(devices), 1, "none", 0)
+                assert sum(multi.bands_taken()) == info["n_bands"] and len(multi.bands_taken()) == len(devices)
+                assert st.kernel_ms > 0.0 and st.gather_ms >= 0.0 and max(multi.worker_ms()) > 0.0
                 # 8-bit frame
                 st = multi.render_device(cam, buf.value, band_rows=band_rows, quantized=True)
                 q = np.zeros(w * h * 3, dtype=np.uint8)
@@ -1152,9 +1156,17 @@ def _full_size_checks(orc, scene, cam, ocam, oworld, n_sample_bands, band_rows=4
 
 
 def test_full_4k_hexagon_groups(gpu, rt, orc):
-    """chapter_14 (327 leaves under 17 groups) at 3840x2160."""
+    """chapter_14 (327 leaves under 17 groups) at 3840x2160: the WHOLE frame against the oracle, every counter, then
+    the checks on row ranges and bands."""
     cam, world, ocam, oworld = load_both(rt, orc, "chapter_14", 3840, 2160)
-    _full_size_checks(orc, world.scene(), cam, ocam, oworld, n_sample_bands=12)
+    scene = world.scene()
+    img, st = scene.render(cam, stats=True)
+    oc = orc.Counters()
+    ref = orc.render(ocam, oworld, threads=16, counters=oc)
+    assert_frames_match(orc, img, ref)
+    counters_equal(st, oc)
+    del ref, img
+    _full_size_checks(orc, scene, cam, ocam, oworld, n_sample_bands=6)
 
 
 def test_full_8k_generated_hierarchy(gpu, rt, orc):
@@ -1168,7 +1180,7 @@ def test_full_8k_generated_hierarchy(gpu, rt, orc):
     cam, world = sf.build_camera(), sf.build_world()
     assert (cam.hsize, cam.vsize) == (7680, 4320)
     ocam, oworld = orc.scene_from_dict(tomli.loads(text))
-    _full_size_checks(orc, world.scene(), cam, ocam, oworld, n_sample_bands=8)
+    _full_size_checks(orc, world.scene(), cam, ocam, oworld, n_sample_bands=16)
 
 
 def test_frame_beyond_four_gigabytes(gpu, rt, orc):

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(rt):
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.rt_abi_version() == 3
+    assert lib.rt_abi_version() == 4
 
 
 def _c_declarations():
@@ -81,7 +81,8 @@ def test_struct_sizes_match_the_header(rt):
 
     names = {"rt_pattern_desc": _lib.PatternDesc, "rt_material_desc": _lib.MaterialDesc,
              "rt_object_desc": _lib.ObjectDesc, "rt_world_desc": _lib.WorldDesc, "rt_camera_desc": _lib.CameraDesc,
-             "rt_stats": _lib.Stats, "rt_render_opts": _lib.RenderOpts, "rt_scene_info": _lib.SceneInfo}
+             "rt_stats": _lib.Stats, "rt_render_opts": _lib.RenderOpts, "rt_scene_info": _lib.SceneInfo,
+             "rt_multi_info": _lib.MultiInfo}
     src = '#include <stdio.h>\n#include "raytracer_rs_amd.h"\nint main(void){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
