@@ -337,34 +337,35 @@ def run_multi_child(args) -> None:
     multi = world.multi_scene(devices)
     create_ms = (time.perf_counter() - t_create) * 1e3
     frame = torch.empty(W * H * 3, dtype=torch.uint8 if u8 else torch.float64, device=dev)
-    band_rows = int(os.environ.get("RT_BENCH_BAND_ROWS", "0"))
+    band_rows = int(os.environ.get("RT_BENCH_BAND_ROWS", "0"))  # developer knobs: stripe height and number of units
+    units = int(os.environ.get("RT_BENCH_UNITS", "0"))
 
     def sync_all():
         for d in sorted(set(devices)):
             torch.cuda.synchronize(d)
 
-    st = multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, stats=True, quantized=u8)
+    st = multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, stats=True, quantized=u8, units=units)
     counts = st.as_dict()
     rays_frame = counts["rays"]
     flops = algorithmic_flops(counts)
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < 0.1:
-        multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, quantized=u8)
+        multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, quantized=u8, units=units)
     prewarm_s = time.perf_counter() - t_pre
     for _ in range(args.warmup):
-        multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, quantized=u8)
+        multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, quantized=u8, units=units)
     sync_all()
     render_ms, gather_ms, taken, worker_ms = [], [], [0] * len(devices), [0.0] * len(devices)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        st = multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, quantized=u8)
+        st = multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, quantized=u8, units=units)
         render_ms.append(st.kernel_ms)
         gather_ms.append(st.gather_ms)
     sync_all()
     elapsed = time.perf_counter() - t0
     # one more (untimed) frame for the per-worker figures
-    multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, quantized=u8)
-    taken, worker_ms, info = multi.bands_taken(), multi.worker_ms(), multi.info()
+    multi.render_device(cam, frame.data_ptr(), band_rows=band_rows, quantized=u8, units=units)
+    taken, worker_ms, info = multi.units_taken(), multi.worker_ms(), multi.info()
 
     scene = world.scene(first)
     stream = torch.cuda.current_stream().cuda_stream
@@ -399,14 +400,14 @@ def run_multi_child(args) -> None:
         "vs_baseline": None,
         "dtype": "f64",
         "data": data_note(args, name),
-        "config": {"workload": f"{name} at {W}x{H}, depth 5; ONE process, a worker thread per GPU, {info['n_bands']} bands of "
-                               f"{info['band_rows']} rows taken from a shared atomic cursor (two in flight per GPU), f64 colours -> "
+        "config": {"workload": f"{name} at {W}x{H}, depth 5; ONE process, a worker thread per GPU, {info['n_units']} units of interleaved "
+                               f"{info['band_rows']}-row stripes taken from a shared atomic cursor (two in flight per GPU), f64 colours -> "
                                + ("8-bit frame (canvas.rs:123-130 applied by the render kernel) " if u8 else "f64 frame ")
                                + f"assembled on GPU {first} ({info['gather']} collection)",
                    "path": "single process, rt_multi_render_device",
                    "rays_per_frame": rays_frame, "rays_per_pixel": round(rays_frame / (W * H), 3)},
         "gather": info["gather"], "rccl_ranks": info["rccl_ranks"], "gather_note": info["note"],
-        "bands": info["n_bands"], "band_rows": info["band_rows"], "bands_taken": taken,
+        "units": info["n_units"], "stripe_rows": info["band_rows"], "units_taken": taken,
         "worker_render_ms": [round(v, 4) for v in worker_ms],
         "render_ms": round(sum(render_ms) / max(1, len(render_ms)), 4),
         "gather_ms": round(sum(gather_ms) / max(1, len(gather_ms)), 4),

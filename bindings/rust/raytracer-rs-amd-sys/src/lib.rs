@@ -156,7 +156,7 @@ pub struct rt_multi_info {
     pub gather: i32,
     pub rccl_ranks: u32,
     pub band_rows: u32,
-    pub n_bands: u32,
+    pub n_units: u32,
     pub note: [c_char; 160],
 }
 
@@ -207,7 +207,7 @@ extern "C" {
     pub fn rt_multi_destroy(multi: *mut rt_multi);
     pub fn rt_multi_render_device(multi: *mut rt_multi, camera: *const rt_camera_desc, opts: *const rt_render_opts, frame_device: *mut c_void, stats: *mut rt_stats) -> c_int;
     pub fn rt_multi_render(multi: *mut rt_multi, camera: *const rt_camera_desc, opts: *const rt_render_opts, rgb: *mut f64, stats: *mut rt_stats) -> c_int;
-    pub fn rt_multi_bands_taken(multi: *const rt_multi, per_worker: *mut u32, n: u32) -> c_int;
+    pub fn rt_multi_units_taken(multi: *const rt_multi, per_worker: *mut u32, n: u32) -> c_int;
     pub fn rt_multi_worker_ms(multi: *const rt_multi, per_worker: *mut f64, n: u32) -> c_int;
     pub fn rt_multi_get_info(multi: *const rt_multi, out: *mut rt_multi_info) -> c_int;
 

@@ -149,6 +149,11 @@ typedef struct rt_render_opts {
  * RT_DEFAULT_DEPTH). */
 #define RT_RENDER_EXACT_DEPTH 4u
 
+/* rt_render_device: `rgb_device` is the WHOLE frame (vsize*hsize*3 values) and every row rendered is stored at its own
+ * place in it, instead of packed from the start of the buffer: a row range or a selection of bands then fills in its
+ * part of a frame that other calls -- other GPUs -- complete. */
+#define RT_RENDER_IN_PLACE 8u
+
 typedef struct rt_scene_info {
     uint32_t n_objects, n_leaves, n_groups, max_nesting;
     uint64_t device_bytes;
@@ -222,44 +227,45 @@ int rt_render_device_noalloc(const rt_scene *scene, const rt_camera_desc *camera
 int rt_scene_render_times(const rt_scene *scene, uint32_t back, double *ordering_ms, double *render_ms);
 
 /* Camera::render's row loop (rendering/camera.rs:58-64) over several GPUs of one node, driven from one process.  The
- * reference renders its rows one after the other on one core; here the frame is cut into bands of rows and every GPU
- * takes the next band from a shared cursor whenever it has fewer than two in flight, so that the GPUs finish together
- * whatever the bands cost.  `devices` lists HIP device ordinals, one worker (host thread, two streams, copies of the
+ * reference renders its rows one after the other on one core; here the frame is cut into stripes of rows, unit u of U
+ * is the set of stripes u, u + U, u + 2U, ... (every unit holds the same mix of cheap and expensive rows), and every GPU
+ * takes the next unit from a shared cursor whenever it has fewer than two in flight, so that the GPUs finish together
+ * whatever their speed.  `devices` lists HIP device ordinals, one worker (host thread, two streams, copies of the
  * world) each; an ordinal may appear more than once (several workers on one GPU).  The frame is assembled on
  * devices[0].  The handle keeps its worker threads until it is destroyed; it serves one call at a time. */
 typedef struct rt_multi rt_multi;
 int rt_multi_create(const rt_world_desc *world, const int *devices, uint32_t n_devices, rt_multi **out);
 void rt_multi_destroy(rt_multi *multi);
-/* How bands rendered on other GPUs reach the frame on devices[0] (rt_multi_render_device); chosen when the handle is
- * created.  RT_GATHER_RCCL: a worker that has issued its last band sends its bands in one group of ncclSend/ncclRecv
- * pairs over its own xGMI link while other GPUs are still rendering (a copy of RCCL already in the process is used,
- * else librccl.so.1 is loaded).  RT_GATHER_COPY: every band is copied behind its kernel by the GPU that rendered it
- * (hipMemcpyPeerAsync) -- taken when RCCL cannot be loaded or initialised, or when the environment says
- * RT_MULTI_GATHER=copy (RT_MULTI_GATHER=rccl makes a missing RCCL an error instead).  RT_GATHER_NONE: every worker is
- * on devices[0]. */
+/* How units rendered on other GPUs reach the frame on devices[0] (rt_multi_render_device); chosen when the handle is
+ * created.  Such a GPU renders a unit's stripes packed, the packed unit travels as one message into staging memory on
+ * devices[0], and a small kernel there puts the stripes in place.  RT_GATHER_RCCL: a worker that has issued its last
+ * unit sends its units in one group of ncclSend/ncclRecv pairs over its own xGMI link while other GPUs are still
+ * rendering (a copy of RCCL already in the process is used, else librccl.so.1 is loaded).  RT_GATHER_COPY: every unit is
+ * copied behind its kernel by the GPU that rendered it (hipMemcpyPeerAsync) -- taken when RCCL cannot be loaded or
+ * initialised, or when the environment says RT_MULTI_GATHER=copy (RT_MULTI_GATHER=rccl makes a missing RCCL an error
+ * instead).  RT_GATHER_NONE: every worker is on devices[0] and renders straight into the frame. */
 enum { RT_GATHER_NONE = 0, RT_GATHER_RCCL = 1, RT_GATHER_COPY = 2 };
 typedef struct rt_multi_info {
     uint32_t n_workers, n_devices; /* workers; distinct GPUs among them */
     int32_t gather;                /* RT_GATHER_* */
     uint32_t rccl_ranks;           /* size of the RCCL communicator, 0 without one */
-    uint32_t band_rows, n_bands;   /* of the last call */
+    uint32_t band_rows, n_units;   /* of the last call: height of a stripe, number of units */
     char note[160];                /* the RCCL library in use, or why RCCL is not */
 } rt_multi_info;
 int rt_multi_get_info(const rt_multi *multi, rt_multi_info *out);
 /* The whole frame into device memory of devices[0] (vsize*hsize*3 doubles, or bytes with RT_RENDER_QUANTIZED), the
- * call returning when it is complete.  Workers on devices[0] render into the frame directly; bands rendered on other
- * GPUs are collected as rt_multi_info.gather says.  Of opts: max_depth, collect_stats, flags (RT_RENDER_QUANTIZED,
- * RT_RENDER_EXACT_DEPTH) and band_rows, the height of a band (0: about four bands per worker but at least 8 192
- * 8x8-pixel tiles each; a single worker takes the frame as one band); everything else must be zero.
- * stats->kernel_ms and stats->gather_ms are wall-clock times (see rt_stats). */
+ * call returning when it is complete.  Of opts: max_depth, collect_stats, flags (RT_RENDER_QUANTIZED,
+ * RT_RENDER_EXACT_DEPTH), band_rows = the height of a stripe (a multiple of 8; 0: 16 rows) and band_step = the number
+ * of units (0: two per worker, fewer for small frames; one worker alone renders the frame in one launch);
+ * everything else must be zero.  stats->kernel_ms and stats->gather_ms are wall-clock times (see rt_stats). */
 int rt_multi_render_device(rt_multi *multi, const rt_camera_desc *camera, const rt_render_opts *opts, void *frame_device,
                            rt_stats *stats);
-/* The same into host memory (Canvas.pixels: vsize*hsize*3 doubles): every GPU sends its bands to the host itself, over
+/* The same into host memory (Canvas.pixels: vsize*hsize*3 doubles): every GPU sends its units to the host itself, over
  * its own PCIe link, and nothing travels between GPUs. */
 int rt_multi_render(rt_multi *multi, const rt_camera_desc *camera, const rt_render_opts *opts, double *rgb, rt_stats *stats);
-/* Measurement aids: how many bands each worker took in the last call, and when each worker's last kernel had finished
+/* Measurement aids: how many units each worker took in the last call, and when each worker's last kernel had finished
  * (milliseconds since the start of that call); n = number of workers. */
-int rt_multi_bands_taken(const rt_multi *multi, uint32_t *per_worker, uint32_t n);
+int rt_multi_units_taken(const rt_multi *multi, uint32_t *per_worker, uint32_t n);
 int rt_multi_worker_ms(const rt_multi *multi, double *per_worker, uint32_t n);
 
 /* World::color_at (rendering/world.rs:113-126) for n rays (6 doubles each: origin xyz, direction xyz) with the

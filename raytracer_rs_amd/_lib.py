@@ -23,6 +23,7 @@ DEFAULT_DEPTH = 5
 RENDER_TIMED = 1
 RENDER_QUANTIZED = 2
 RENDER_EXACT_DEPTH = 4
+RENDER_IN_PLACE = 8
 MAX_DEPTH = 8
 NOALLOC_MAX_TILES = 524288
 
@@ -96,7 +97,7 @@ class RenderOpts(C.Structure):
 
 class MultiInfo(C.Structure):
     _fields_ = [("n_workers", C.c_uint32), ("n_devices", C.c_uint32), ("gather", C.c_int32), ("rccl_ranks", C.c_uint32),
-                ("band_rows", C.c_uint32), ("n_bands", C.c_uint32), ("note", C.c_char * 160)]
+                ("band_rows", C.c_uint32), ("n_units", C.c_uint32), ("note", C.c_char * 160)]
 
 
 GATHER_NAMES = {0: "none", 1: "rccl", 2: "copy"}
@@ -124,7 +125,7 @@ SIGNATURES = {
     "rt_multi_destroy": (None, [C.c_void_p]),
     "rt_multi_render_device": (C.c_int, [C.c_void_p, _P(CameraDesc), _P(RenderOpts), C.c_void_p, _P(Stats)]),
     "rt_multi_render": (C.c_int, [C.c_void_p, _P(CameraDesc), _P(RenderOpts), _P(C.c_double), _P(Stats)]),
-    "rt_multi_bands_taken": (C.c_int, [C.c_void_p, _P(C.c_uint32), C.c_uint32]),
+    "rt_multi_units_taken": (C.c_int, [C.c_void_p, _P(C.c_uint32), C.c_uint32]),
     "rt_multi_worker_ms": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32]),
     "rt_multi_get_info": (C.c_int, [C.c_void_p, _P(MultiInfo)]),
     "rt_color_at": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_uint32, C.c_int32, _P(C.c_double), _P(Stats)]),

@@ -333,16 +333,16 @@ class Scene:
 
     def render_device(self, camera: "Camera", device_ptr: int, rows: Optional[Tuple[int, int]] = None,
                       max_depth: Optional[int] = None, stream: int = 0, stats: bool = False, timed: bool = False,
-                      quantized: bool = False) -> Optional[L.Stats]:
+                      quantized: bool = False, in_place: bool = False) -> Optional[L.Stats]:
         """rt_render_device: asynchronous launch on `stream` into device memory at `device_ptr`
-        ((row_end-row_begin)*hsize*3 doubles)."""
+        ((row_end-row_begin)*hsize*3 doubles; with `in_place` the whole frame, the rows landing at their own place)."""
         cd = camera._desc()
         opts = L.RenderOpts()
         if rows is not None:
             opts.row_begin, opts.row_end = rows
         opts.collect_stats = int(stats)
         opts.stream = C.c_void_p(stream)
-        opts.flags = (L.RENDER_TIMED if timed else 0) | (L.RENDER_QUANTIZED if quantized else 0)
+        opts.flags = (L.RENDER_TIMED if timed else 0) | (L.RENDER_QUANTIZED if quantized else 0) | (L.RENDER_IN_PLACE if in_place else 0)
         _set_depth(opts, max_depth)
         st = L.Stats()
         L.check(L.lib().rt_render_device(self._h, C.byref(cd), C.byref(opts), C.c_void_p(device_ptr), C.byref(st)))
@@ -350,15 +350,15 @@ class Scene:
 
     def render_device_bands(self, camera: "Camera", device_ptr: int, band_rows: int, band_first: int, band_step: int,
                             max_depth: Optional[int] = None, stream: int = 0, stats: bool = False, timed: bool = False,
-                            quantized: bool = False) -> Optional[L.Stats]:
+                            quantized: bool = False, in_place: bool = False) -> Optional[L.Stats]:
         """rt_render_device restricted to bands band_first, band_first+band_step, ... of band_rows rows each; the
-        bands are written one after another at `device_ptr`."""
+        bands are written one after another at `device_ptr` (with `in_place`: at their own rows of the whole frame there)."""
         cd = camera._desc()
         opts = L.RenderOpts()
         opts.band_rows, opts.band_first, opts.band_step = band_rows, band_first, band_step
         opts.collect_stats = int(stats)
         opts.stream = C.c_void_p(stream)
-        opts.flags = (L.RENDER_TIMED if timed else 0) | (L.RENDER_QUANTIZED if quantized else 0)
+        opts.flags = (L.RENDER_TIMED if timed else 0) | (L.RENDER_QUANTIZED if quantized else 0) | (L.RENDER_IN_PLACE if in_place else 0)
         _set_depth(opts, max_depth)
         st = L.Stats()
         L.check(L.lib().rt_render_device(self._h, C.byref(cd), C.byref(opts), C.c_void_p(device_ptr), C.byref(st)))
@@ -491,39 +491,40 @@ class MultiScene:
         except Exception:
             pass
 
-    def _opts(self, band_rows: int, max_depth: Optional[int], stats: bool, quantized: bool) -> L.RenderOpts:
+    def _opts(self, band_rows: int, max_depth: Optional[int], stats: bool, quantized: bool, units: int = 0) -> L.RenderOpts:
         opts = L.RenderOpts()
-        opts.band_rows = band_rows
+        opts.band_rows = band_rows  # height of a stripe (0: the library's 16)
+        opts.band_step = units      # number of interleaved units (0: two per worker)
         opts.collect_stats = int(stats)
         opts.flags = L.RENDER_QUANTIZED if quantized else 0
         _set_depth(opts, max_depth)
         return opts
 
     def render(self, camera: "Camera", band_rows: int = 0, max_depth: Optional[int] = None, stats: bool = False,
-               out: Optional[np.ndarray] = None):
+               out: Optional[np.ndarray] = None, units: int = 0):
         """rt_multi_render into a host array [vsize, hsize, 3]; returns (array, Stats)."""
         cd = camera._desc()
         if out is None:
             out = np.zeros((camera.vsize, camera.hsize, 3), dtype=np.float64)
         _check_frame(out, camera)
-        opts = self._opts(band_rows, max_depth, stats, False)
+        opts = self._opts(band_rows, max_depth, stats, False, units)
         st = L.Stats()
         L.check(L.lib().rt_multi_render(self._h, C.byref(cd), C.byref(opts), out.ctypes.data_as(C.POINTER(C.c_double)),
                                         C.byref(st)))
         return out, st
 
     def render_device(self, camera: "Camera", device_ptr: int, band_rows: int = 0, max_depth: Optional[int] = None,
-                      stats: bool = False, quantized: bool = False) -> L.Stats:
+                      stats: bool = False, quantized: bool = False, units: int = 0) -> L.Stats:
         """rt_multi_render_device: the whole frame into memory of devices[0] at `device_ptr`; returns when complete."""
         cd = camera._desc()
-        opts = self._opts(band_rows, max_depth, stats, quantized)
+        opts = self._opts(band_rows, max_depth, stats, quantized, units)
         st = L.Stats()
         L.check(L.lib().rt_multi_render_device(self._h, C.byref(cd), C.byref(opts), C.c_void_p(device_ptr), C.byref(st)))
         return st
 
-    def bands_taken(self) -> List[int]:
+    def units_taken(self) -> List[int]:
         arr = (C.c_uint32 * len(self.devices))()
-        L.check(L.lib().rt_multi_bands_taken(self._h, arr, len(self.devices)))
+        L.check(L.lib().rt_multi_units_taken(self._h, arr, len(self.devices)))
         return list(arr)
 
     def worker_ms(self) -> List[float]:
@@ -537,7 +538,7 @@ class MultiScene:
         mi = L.MultiInfo()
         L.check(L.lib().rt_multi_get_info(self._h, C.byref(mi)))
         return {"n_workers": mi.n_workers, "n_devices": mi.n_devices, "gather": L.GATHER_NAMES.get(mi.gather, str(mi.gather)),
-                "rccl_ranks": mi.rccl_ranks, "band_rows": mi.band_rows, "n_bands": mi.n_bands, "note": mi.note.decode(errors="replace")}
+                "rccl_ranks": mi.rccl_ranks, "band_rows": mi.band_rows, "n_units": mi.n_units, "note": mi.note.decode(errors="replace")}
 
 
 def _check_frame(out: np.ndarray, camera: "Camera") -> None:

@@ -42,9 +42,18 @@ struct rt_scene {
     uint32_t *d_tiles = nullptr;  // tile-ordering scratch of launch_render, grown on demand
     size_t tiles_cap = 0;         // in 32-bit words
     bool uneven = false;          // tiles differ in cost by more than a shadow ray: ordering them pays
-    bool order_valid = false;     // d_tiles holds the launch order for (order_cam, order_rows)
-    RtCameraDev order_cam{};
-    uint32_t order_rows[5] = {};
+    // Launch orders worked out so far, each in scratch of its own, keyed by the view they belong to (camera and rows):
+    // a caller that renders the same rows through the same camera again -- a frame loop, the bands of rt_multi --
+    // finds the order ready.  Least recently used entries make room (ORDER_CACHE_ENTRIES, ORDER_CACHE_BYTES).
+    struct OrderEntry {
+        RtCameraDev cam{};
+        uint32_t rows[5] = {};
+        uint32_t *d_tiles = nullptr;
+        size_t cap = 0;  // in 32-bit words
+        uint64_t used = 0;
+    };
+    std::vector<OrderEntry> orders;
+    uint64_t order_clock = 0;
     hipEvent_t marks[32][3] = {};  // event triples of the launches made with RT_RENDER_TIMED, used round-robin
     uint32_t timed_launches = 0;
     RenderPipe pipe;
@@ -126,7 +135,8 @@ int render_rows(const rt_scene *scene, const rt_camera_desc *camera, const rt_re
         if (opts->max_depth < 0 || opts->max_depth > RT_MAX_DEPTH)
             return set_error(RT_ERR_INVALID_ARGUMENT, "max_depth must be within 0.." + std::to_string(RT_MAX_DEPTH));
         depth = (opts->flags & RT_RENDER_EXACT_DEPTH) ? opts->max_depth : clamp_depth(opts->max_depth);
-        if (opts->flags & ~(RT_RENDER_TIMED | RT_RENDER_QUANTIZED | RT_RENDER_EXACT_DEPTH)) return set_error(RT_ERR_INVALID_ARGUMENT, "unknown bits in flags");
+        if (opts->flags & ~(RT_RENDER_TIMED | RT_RENDER_QUANTIZED | RT_RENDER_EXACT_DEPTH | RT_RENDER_IN_PLACE)) return set_error(RT_ERR_INVALID_ARGUMENT, "unknown bits in flags");
+        rows.in_place = (opts->flags & RT_RENDER_IN_PLACE) ? 1u : 0u;
         if (opts->band_rows) {
             if (opts->band_step == 0) return set_error(RT_ERR_INVALID_ARGUMENT, "band_step must be positive");
             const uint32_t n_bands = (camera->vsize + opts->band_rows - 1) / opts->band_rows;
@@ -279,6 +289,8 @@ void rt_scene_destroy(rt_scene *scene) {
         if (scene->d_surfaces) (void)hipFree(scene->d_surfaces);
         if (scene->d_counters) (void)hipFree(scene->d_counters);
         if (scene->d_tiles) (void)hipFree(scene->d_tiles);
+        for (auto &e : scene->orders)
+            if (e.d_tiles) (void)hipFree(e.d_tiles);
         RenderPipe &p = scene->pipe;
         if (p.d_frame) (void)hipFree(p.d_frame);
         if (p.h_stage) (void)hipHostFree(p.h_stage);
@@ -324,6 +336,7 @@ static bool tile_order_cache_enabled() {
 // this camera -- the order is a function of world, camera and rows only, so a caller that renders the same view again
 // (a frame loop, a benchmark) need not have it worked out again.  Callers that pass nullptr share the scratch between
 // launches over different rows and get no caching.
+enum : size_t { ORDER_CACHE_ENTRIES = 64, ORDER_CACHE_BYTES = 64u << 20 };
 static hipError_t tile_scratch(const rt_scene *scene_c, const rt_camera_desc *camera, const rt::RowMap &rows, const RtCameraDev *cam,
                                uint32_t **out, bool *cached) {
     *out = nullptr;
@@ -331,28 +344,47 @@ static hipError_t tile_scratch(const rt_scene *scene_c, const rt_camera_desc *ca
     if (!tile_order_enabled() || rows.n_rows == 0 || !scene_c->uneven) return hipSuccess;
     rt_scene *scene = const_cast<rt_scene *>(scene_c);
     const size_t need = rt::render_scratch_words(camera->hsize, rows.n_rows);
-    if (need > scene->tiles_cap) {
-        if (scene->d_tiles) (void)hipFree(scene->d_tiles);
-        scene->d_tiles = nullptr;
-        scene->tiles_cap = 0;
-        scene->order_valid = false;
-        hipError_t e = hipMalloc((void **)&scene->d_tiles, need * sizeof(uint32_t));
-        if (e != hipSuccess) return e;
-        scene->tiles_cap = need;
-    }
-    *out = scene->d_tiles;
-    if (!cached || !cam || !tile_order_cache_enabled()) {
-        scene->order_valid = false;
+    if (!cached || !cam || !tile_order_cache_enabled()) {  // the handle's one shared scratch
+        if (need > scene->tiles_cap) {
+            if (scene->d_tiles) (void)hipFree(scene->d_tiles);
+            scene->d_tiles = nullptr;
+            scene->tiles_cap = 0;
+            hipError_t e = hipMalloc((void **)&scene->d_tiles, need * sizeof(uint32_t));
+            if (e != hipSuccess) return e;
+            scene->tiles_cap = need;
+        }
+        *out = scene->d_tiles;
         return hipSuccess;
     }
     const uint32_t key[5] = {rows.row_begin, rows.row_end, rows.n_rows, rows.band_rows, rows.band_pitch};
-    if (scene->order_valid && std::memcmp(&scene->order_cam, cam, sizeof *cam) == 0 && std::memcmp(scene->order_rows, key, sizeof key) == 0) {
-        *cached = true;
-    } else {
-        scene->order_cam = *cam;
-        std::memcpy(scene->order_rows, key, sizeof key);
-        scene->order_valid = true;
+    auto &orders = scene->orders;
+    for (auto &e : orders)
+        if (std::memcmp(&e.cam, cam, sizeof *cam) == 0 && std::memcmp(e.rows, key, sizeof key) == 0 && e.cap >= need) {
+            e.used = ++scene->order_clock;
+            *out = e.d_tiles;
+            *cached = true;
+            return hipSuccess;
+        }
+    // a new view: an entry of its own, after the least recently used ones have made room
+    size_t total = need * sizeof(uint32_t);
+    for (const auto &e : orders) total += e.cap * sizeof(uint32_t);
+    while (!orders.empty() && (orders.size() >= ORDER_CACHE_ENTRIES || total > ORDER_CACHE_BYTES)) {
+        size_t lru = 0;
+        for (size_t k = 1; k < orders.size(); ++k)
+            if (orders[k].used < orders[lru].used) lru = k;
+        total -= orders[lru].cap * sizeof(uint32_t);
+        (void)hipFree(orders[lru].d_tiles);  // (waits for the device: nothing that reads the entry is still running)
+        orders.erase(orders.begin() + (std::ptrdiff_t)lru);
     }
+    rt_scene::OrderEntry e;
+    hipError_t err = hipMalloc((void **)&e.d_tiles, need * sizeof(uint32_t));
+    if (err != hipSuccess) return err;
+    e.cap = need;
+    e.cam = *cam;
+    std::memcpy(e.rows, key, sizeof key);
+    e.used = ++scene->order_clock;
+    orders.push_back(e);
+    *out = e.d_tiles;
     return hipSuccess;
 }
 

@@ -1608,12 +1608,16 @@ __global__ __launch_bounds__(RENDER_BLOCK, NEST > 0 ? RT_NEST_WAVES : 4) void re
     // instead laid out in LDS as its 8 rows of 24 values (the pending-ray stack is empty by now and lends the space)
     // and stored row by row with consecutive lanes on consecutive words: 8-byte stores covering 192 contiguous bytes
     // per tile row for the f64 canvas, one dword per lane for the 8-bit frame.
-    const size_t idx = ((size_t)r * cam.hsize + x) * 3;  // Canvas index (canvas.rs:40-42) within the rows rendered
-    const bool whole_tile = __ballot(valid) == ~0ull;
+    // Where the rows land: packed one after the other from the start of the buffer, or (rows.in_place) at their own
+    // place in a whole frame.  A tile's eight rows are consecutive frame rows when bands are whole tiles high.
+    const unsigned r_out = rows.in_place ? y : r;
+    const unsigned tile_row_out = rows.in_place ? image_row(rows, (tile / tiles_x) * 8) : (tile / tiles_x) * 8;
+    const size_t idx = ((size_t)r_out * cam.hsize + x) * 3;  // Canvas index (canvas.rs:40-42)
+    const bool whole_tile = __ballot(valid) == ~0ull && (!rows.in_place || (rows.band_rows & 7u) == 0u);
     if (rows.quantized) {
         const unsigned q0 = quantize_value(acc.x), q1 = quantize_value(acc.y), q2 = quantize_value(acc.z);
         const size_t row_bytes = (size_t)cam.hsize * 3;
-        uint8_t *tile0 = rows.quantized + (size_t)((tile / tiles_x) * 8) * row_bytes + (size_t)((tile % tiles_x) * 8) * 3;
+        uint8_t *tile0 = rows.quantized + (size_t)tile_row_out * row_bytes + (size_t)((tile % tiles_x) * 8) * 3;
         if (whole_tile && ((row_bytes | reinterpret_cast<size_t>(rows.quantized)) & 3) == 0) {
             uint8_t *bytes = reinterpret_cast<uint8_t *>(ray_stack_lds + S.stack_base);  // 8 rows x 24 bytes
             const unsigned at = (lane >> 3) * 24 + (lane & 7) * 3;
@@ -1638,7 +1642,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, NEST > 0 ? RT_NEST_WAVES : 4) void re
         vals[at + 1] = acc.y;
         vals[at + 2] = acc.z;
         __builtin_amdgcn_wave_barrier();
-        double *tile0 = rgb + ((size_t)((tile / tiles_x) * 8) * cam.hsize + (size_t)((tile % tiles_x) * 8)) * 3;
+        double *tile0 = rgb + ((size_t)tile_row_out * cam.hsize + (size_t)((tile % tiles_x) * 8)) * 3;
 #pragma unroll
         for (unsigned k = 0; k < 3; ++k) {
             const unsigned j = lane + 64 * k;  // 192 values
@@ -1916,6 +1920,17 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict_
     }
 }
 
+// Packed stripes -> their places in a frame (the collection step of a frame rendered on several GPUs): word i of the
+// packed source belongs to stripe i / stripe_words.  T is the widest word that divides every size and address involved.
+template <typename T>
+__global__ __launch_bounds__(256) void place_stripes_kernel(const T *__restrict__ src, T *__restrict__ dst, size_t stripe_words,
+                                                           size_t dst_pitch_words, size_t total_words) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_words) return;
+    const size_t stripe = i / stripe_words;
+    dst[stripe * dst_pitch_words + (i - stripe * stripe_words)] = src[i];
+}
+
 inline unsigned blocks_for(unsigned n) { return (n + 255u) / 256u; }
 
 }  // namespace
@@ -2090,6 +2105,24 @@ hipError_t launch_quantize(const double *rgb, size_t n, uint8_t *out, hipStream_
     const size_t per_block = 256 * 8;
     quantize_kernel<<<(unsigned)((n + per_block - 1) / per_block), 256, 0, stream>>>(rgb, n, out);
     return hipGetLastError();
+}
+
+hipError_t launch_place_stripes(const void *src, void *dst, size_t stripe_bytes, size_t dst_pitch_bytes, size_t total_bytes,
+                                hipStream_t stream) {
+    if (total_bytes == 0) return hipSuccess;
+    if (stripe_bytes == 0) return hipErrorInvalidValue;
+    const size_t all = stripe_bytes | dst_pitch_bytes | total_bytes | reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst);
+    auto launch = [&](auto word) {
+        using T = decltype(word);
+        const size_t n = total_bytes / sizeof(T);
+        if ((n + 255) / 256 > 0x7fffffffull) return hipErrorInvalidValue;
+        place_stripes_kernel<T><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(static_cast<const T *>(src), static_cast<T *>(dst),
+                                                                                stripe_bytes / sizeof(T), dst_pitch_bytes / sizeof(T), n);
+        return hipGetLastError();
+    };
+    if ((all & 15) == 0) return launch(uint4{});
+    if ((all & 3) == 0) return launch(uint32_t{});
+    return launch(uint8_t{});
 }
 
 hipError_t launch_ray_for_pixel(const RtCameraDev &camera, const uint32_t *px, const uint32_t *py, uint32_t n,

@@ -34,6 +34,8 @@ struct RowMap {
     const uint32_t *tile_list = nullptr;  // set by launch_render
     uint8_t *quantized = nullptr;         // when set, the frame is stored here as 8-bit values (3 bytes per pixel, the
                                           // canvas quantiser applied in the kernel) and `rgb` is not written
+    uint32_t in_place = 0;                // non-zero: the output buffer is the WHOLE frame and a row lands at its own place
+                                          // in it (index = frame row), not packed after the rows rendered before it
 };
 
 // Number of 32-bit words of device scratch launch_render needs for a frame of hsize x n_rows pixels.
@@ -55,6 +57,10 @@ hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, co
 // array holds render_scratch_words() words for frames of up to RT_NOALLOC_MAX_TILES tiles.
 hipError_t static_render_scratch_resolve(int device);
 uint32_t *static_render_scratch(int device);
+// Stripes of rows that lie packed one after the other at `src` go to their places in a frame: stripe k (stripe_bytes
+// long, the last one possibly shorter; total_bytes in all) to dst + k * dst_pitch_bytes.  Both on the current device.
+hipError_t launch_place_stripes(const void *src, void *dst, size_t stripe_bytes, size_t dst_pitch_bytes, size_t total_bytes,
+                                hipStream_t stream);
 // The canvas quantiser (rendering/canvas.rs:123-130) over n values in device memory.
 hipError_t launch_quantize(const double *rgb, size_t n, uint8_t *out, hipStream_t stream);
 // World::color_at for n rays.

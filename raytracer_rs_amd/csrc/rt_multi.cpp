@@ -1,25 +1,33 @@
 // One frame over several GPUs of a node, from one process: the row loop of Camera::render (rendering/camera.rs:58-64)
-// cut into bands that the GPUs take from a shared cursor as they become free (a band costs anything between one ray
-// per pixel in the sky and dozens on glass, so who renders what is decided at run time, not dealt in advance).  The
-// world is small and read-only: every GPU holds its own copies (rt_scene handles).  Built on the public C ABI plus the
-// HIP runtime.
+// cut into units of work that the GPUs take from a shared cursor as they become free, so who renders what is decided
+// at run time, not dealt in advance.  The world is small and read-only: every GPU holds its own copies (rt_scene
+// handles).  Built on the public C ABI plus the HIP runtime.
+//
+// Units.  The frame is cut into stripes of `band_rows` rows (16 unless the caller says otherwise) and unit u of U is
+// the set of stripes u, u + U, u + 2U, ...: every unit holds the same mix of sky, floor and glass, so units cost about
+// the same and one launch per unit sees the whole frame's spread of tile costs (contiguous bands of rows differ by an
+// order of magnitude in cost and each ends in a tail of its own slowest tiles: measured on one GPU's share of a
+// 3840x2160 chapter_11 frame, interleaved units are 4-10 % faster than contiguous bands of the same size).  Two units
+// per worker by default: one per stream of a worker, the next one taken by whichever GPU is free first.
 //
 // Workers.  One per entry of `devices`: a host thread that lives as long as the handle (the caller's thread drives
-// worker 0), with two slots -- a stream, a scene handle and two events each -- so that two bands are in flight on its
-// GPU at any time, on two streams: the under-occupied end of one band's launch overlaps the start of the next.
+// worker 0), with two slots -- a stream, a scene handle and two events each -- so that two units are in flight on its
+// GPU at any time: the under-occupied end of one launch overlaps the start of the next.
 //
-// Collection of the frame on devices[0].  Workers on that GPU render straight into the frame.  For the others there
-// are two ways, both overlapped with the rendering that is still going on elsewhere:
-//   RT_GATHER_RCCL   a worker that has issued its last band sends its bands with RCCL -- one group of ncclSend /
-//                    ncclRecv pairs, runs of consecutive bands as one message, on a communicator from ncclCommInitAll
-//                    over the distinct GPUs -- over its own xGMI link; the receives run on a stream of devices[0] that
-//                    belongs to that worker.  RCCL is looked for among the libraries already in the process first (a
-//                    host program such as PyTorch brings its own copy; two copies in one process would each set up
-//                    their own transports) and loaded by name otherwise, so the library itself depends on the HIP
-//                    runtime only.
-//   RT_GATHER_COPY   every band is copied by the GPU that rendered it (hipMemcpyPeerAsync on the band's stream, behind
-//                    its kernel): no communicator, no library; used when RCCL is not available, cannot be
-//                    initialised, or RT_MULTI_GATHER=copy is set in the environment.
+// Collection of the frame on devices[0].  Workers on that GPU render their stripes straight into the frame
+// (RT_RENDER_IN_PLACE).  The others render a unit's stripes packed one after the other; the packed unit travels as ONE
+// message into staging memory on devices[0] and a small kernel there puts its stripes in place.  Two ways to travel,
+// both overlapped with the rendering that is still going on elsewhere:
+//   RT_GATHER_RCCL   a worker that has issued its last unit sends its units with RCCL -- one group of ncclSend /
+//                    ncclRecv pairs on a communicator from ncclCommInitAll over the distinct GPUs -- over its own
+//                    xGMI link; the receives and the placement run on a stream of devices[0] that belongs to that
+//                    worker.  RCCL is looked for among the libraries already in the process first (a host program
+//                    such as PyTorch brings its own copy; two copies in one process would each set up their own
+//                    transports) and loaded by name otherwise, so the library itself depends on the HIP runtime only.
+//   RT_GATHER_COPY   every unit is copied by the GPU that rendered it (hipMemcpyPeerAsync on the unit's stream, behind
+//                    its kernel), and the placement on devices[0] waits for that copy's event: no communicator, no
+//                    library; used when RCCL is not available, cannot be initialised, or RT_MULTI_GATHER=copy is set
+//                    in the environment.
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 
@@ -38,6 +46,7 @@
 
 #include "../../include/raytracer_rs_amd.h"
 #include "rt_capi_internal.hpp"
+#include "rt_device.hpp"
 
 namespace {
 
@@ -134,7 +143,7 @@ struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t rendered = nullptr;  // behind the band's kernel
     hipEvent_t done = nullptr;      // behind the band's transfer, if it has one (else behind the kernel)
-    uint32_t band = UINT32_MAX;     // in flight
+    uint32_t band = UINT32_MAX;     // the unit in flight
 };
 
 struct Worker {
@@ -142,10 +151,10 @@ struct Worker {
     int rank = -1;              // index of `device` among the distinct devices (= its rank in the communicator)
     bool on_first = false;      // renders straight into the frame: same GPU as devices[0]
     Slot slot[2];
-    hipStream_t recv = nullptr;  // on devices[0]: where this worker's bands are received (RCCL collection)
-    char *d_buf = nullptr;       // this GPU's bands, at the offsets they have in the frame (workers not on the first GPU,
-    size_t d_cap = 0;            // and every worker of rt_multi_render)
-    std::vector<uint32_t> mine;  // bands taken during the current call
+    hipStream_t recv = nullptr;  // on devices[0]: where this worker's units are received and put in place
+    char *d_buf = nullptr;       // this GPU's units, packed (workers not on the first GPU, and every worker of
+    size_t d_cap = 0;            // rt_multi_render)
+    std::vector<uint32_t> mine;  // units taken during the current call
     rt_stats stats{};
     double rendered_ms = 0.0, finished_ms = 0.0;  // since the start of the call: last kernel done; last band delivered
     int rc = RT_OK;
@@ -154,18 +163,21 @@ struct Worker {
 };
 
 struct Plan {
-    uint32_t band_rows = 0, n_bands = 0;
+    uint32_t band_rows = 0;  // height of a stripe
+    uint32_t n_units = 0;    // unit u = stripes u, u + n_units, ...
+    uint32_t n_stripes = 0;
     size_t row_bytes = 0;
     uint32_t flags = 0;
     int32_t max_depth = 0;
     bool stats = false;
+    std::vector<uint32_t> unit_rows;  // rows of unit u
+    std::vector<size_t> unit_off;     // where unit u starts in a buffer that holds all units packed, in bytes (n_units + 1)
 };
 
 struct Job {
     rt_camera_desc camera{};
     Plan plan;
-    char *frame_on_first = nullptr;  // where workers on the first GPU render to (nullptr: every worker into its own buffer)
-    char *frame_device = nullptr;    // the frame on devices[0] that bands of other GPUs are collected into (or nullptr)
+    char *frame_device = nullptr;    // the frame on devices[0] (workers there render into it, other GPUs' units are collected into it), or nullptr
     char *stage = nullptr, *rgb = nullptr;  // host frame: pinned staging memory and the caller's buffer
     Clock::time_point t0;
 };
@@ -180,7 +192,10 @@ struct rt_multi {
     std::string gather_note;          // why RCCL is not in use, when it was wanted
     char *h_stage = nullptr;          // pinned staging memory of rt_multi_render, the size of the frame
     size_t h_cap = 0;
-    std::vector<uint32_t> last_taken; // bands per worker in the last call
+    char *stage0 = nullptr;           // on devices[0]: where packed units of other GPUs arrive, the size of the frame
+    size_t stage0_cap = 0;
+    bool test_peers = false;          // RT_MULTI_TEST_PEERS=1: workers other than the first are treated as if on another GPU
+    std::vector<uint32_t> last_taken; // units per worker in the last call
     std::vector<double> last_ms;      // per worker: when its last kernel had finished, since the start of the call
     Plan last_plan;
     // the job the worker threads wait for
@@ -226,38 +241,49 @@ void add_stats(rt_stats &into, const rt_stats &s) {
     into.specular += s.specular; into.patterns += s.patterns; into.refract_setups += s.refract_setups; into.schlick += s.schlick;
 }
 
-// Height of a band when the caller names none.  A launch fills the GPU with 4 096 waves of one 8x8-pixel tile each and
-// ends with a tail of its slowest tiles, so a band should be a few such generations; more bands than workers let a GPU
-// that drew cheap rows take another.  Aim at four bands per worker, but never fewer than 8 192 tiles per band; one
-// worker alone takes the frame as one band (exactly what rt_render_device does).
-uint32_t default_band_rows(const rt_camera_desc &camera, size_t n_workers) {
-    const uint32_t whole = (camera.vsize + 7u) / 8u * 8u;
-    if (n_workers <= 1) return whole;
-    const uint64_t tiles_x = (camera.hsize + 7u) / 8u;
-    const uint64_t tiles = tiles_x * ((camera.vsize + 7u) / 8u);
-    const uint64_t per_band = std::max<uint64_t>(8192u, tiles / (4u * n_workers));
-    const uint64_t tile_rows = std::max<uint64_t>(1u, (per_band + tiles_x - 1u) / tiles_x);
-    return (uint32_t)std::min<uint64_t>(whole, tile_rows * 8u);
+// Into how many units the frame is cut when the caller names no number: two per worker (one for each of its
+// streams), fewer when a unit would hold less than 2 048 of the 8x8-pixel tiles a launch hands to its waves (a GPU
+// runs 4 096 waves at a time); one worker alone takes the frame as one unit (exactly what rt_render_device does).
+uint32_t default_units(const rt_camera_desc &camera, size_t n_workers, uint32_t n_stripes) {
+    if (n_workers <= 1) return 1;
+    const uint64_t tiles = (uint64_t)((camera.hsize + 7u) / 8u) * ((camera.vsize + 7u) / 8u);
+    uint64_t units = 2u * n_workers;
+    while (units > n_workers && tiles / units < 2048u) --units;
+    return (uint32_t)std::max<uint64_t>(1u, std::min<uint64_t>(units, n_stripes));
 }
 
-// Validates a multi-GPU render call and cuts the frame into bands.
+// Validates a multi-GPU render call and cuts the frame into units.
 int make_plan(const rt_multi *m, const rt_camera_desc *camera, const rt_render_opts *opts, bool device_frame, Plan &plan) {
     if (!m || !camera) return rt::capi_set_error(RT_ERR_INVALID_ARGUMENT, "multi and camera must not be NULL");
     if (camera->hsize == 0 || camera->vsize == 0) return rt::capi_set_error(RT_ERR_INVALID_ARGUMENT, "camera has zero size");
     plan = Plan{};
     if (opts) {
-        if (opts->row_begin || opts->row_end || opts->band_first || opts->band_step || opts->stream)
-            return rt::capi_set_error(RT_ERR_INVALID_ARGUMENT, "rt_multi_render* renders whole frames on its own streams: row range, band selection and stream must be zero");
+        if (opts->row_begin || opts->row_end || opts->band_first || opts->stream)
+            return rt::capi_set_error(RT_ERR_INVALID_ARGUMENT, "rt_multi_render* renders whole frames on its own streams: row range, band_first and stream must be zero");
         const uint32_t allowed = RT_RENDER_EXACT_DEPTH | (device_frame ? RT_RENDER_QUANTIZED : 0u);
         if (opts->flags & ~allowed) return rt::capi_set_error(RT_ERR_INVALID_ARGUMENT, "flags not available for this call");
+        if (opts->band_rows % 8u) return rt::capi_set_error(RT_ERR_INVALID_ARGUMENT, "band_rows must be a multiple of 8, the height of a tile");
         plan.flags = opts->flags;
         plan.max_depth = opts->max_depth;
         plan.stats = opts->collect_stats != 0;
         plan.band_rows = opts->band_rows;
+        plan.n_units = opts->band_step;
     }
-    if (plan.band_rows == 0) plan.band_rows = default_band_rows(*camera, m->workers.size());
-    plan.n_bands = (camera->vsize + plan.band_rows - 1) / plan.band_rows;
+    if (m->workers.size() == 1 && plan.n_units == 0 && plan.band_rows == 0) plan.band_rows = (camera->vsize + 7u) / 8u * 8u;  // the frame as one launch
+    if (plan.band_rows == 0) plan.band_rows = 16;
+    plan.n_stripes = (camera->vsize + plan.band_rows - 1) / plan.band_rows;
+    if (plan.n_units == 0) plan.n_units = default_units(*camera, m->workers.size(), plan.n_stripes);
+    plan.n_units = std::min(plan.n_units, plan.n_stripes);
     plan.row_bytes = (size_t)camera->hsize * 3 * ((plan.flags & RT_RENDER_QUANTIZED) ? 1 : sizeof(double));
+    plan.unit_rows.assign(plan.n_units, 0);
+    plan.unit_off.assign(plan.n_units + 1, 0);
+    for (uint32_t st = 0; st < plan.n_stripes; ++st)
+        plan.unit_rows[st % plan.n_units] += std::min(plan.band_rows, camera->vsize - st * plan.band_rows);
+    for (uint32_t u = 0; u < plan.n_units; ++u) {
+        // (packed units start on 256-byte boundaries: the placement kernel and the transports like aligned messages)
+        const size_t bytes = ((size_t)plan.unit_rows[u] * plan.row_bytes + 255u) / 256u * 256u;
+        plan.unit_off[u + 1] = plan.unit_off[u] + bytes;
+    }
     return RT_OK;
 }
 
@@ -267,43 +293,52 @@ void worker_failed(Worker &w, int rc, const std::string &what) {
     w.err = what;
 }
 
-// RCCL collection of one worker's bands into the frame on devices[0]: runs of consecutive bands as one message, all of
-// them in one group; the sends wait for both of the worker's streams, the receives run on the worker's stream on
-// devices[0].  Called by the worker's thread once it has issued its last band; returns when the bands have arrived.
-void collect_with_rccl(rt_multi *m, Worker &w, const Job &job, size_t frame_bytes) {
+// A packed unit that has arrived in the staging memory on devices[0] is put in place: its stripes go to their rows of
+// the frame.  Queued on `stream`, a stream of devices[0].
+hipError_t place_unit(const rt_multi *m, const Job &job, uint32_t u, hipStream_t stream) {
+    const Plan &plan = job.plan;
+    if (plan.unit_rows[u] == 0) return hipSuccess;
+    DeviceScope first(m->workers[0].device);
+    const size_t stripe_bytes = (size_t)plan.band_rows * plan.row_bytes;
+    return rt::launch_place_stripes(m->stage0 + plan.unit_off[u], job.frame_device + (size_t)u * stripe_bytes, stripe_bytes,
+                                    (size_t)plan.n_units * stripe_bytes, (size_t)plan.unit_rows[u] * plan.row_bytes, stream);
+}
+
+// RCCL collection of one worker's units into the frame on devices[0]: every unit one message, all of them in one group;
+// the sends wait for both of the worker's streams, the receives run on the worker's stream on devices[0], and so does
+// the placement of the stripes behind them.  Called by the worker's thread once it has issued its last unit; returns
+// when its part of the frame is complete.
+void collect_with_rccl(rt_multi *m, Worker &w, const Job &job) {
     if (w.mine.empty()) return;
     hipError_t e = hipStreamWaitEvent(w.slot[0].stream, w.slot[1].rendered, 0);  // (an event never recorded counts as complete)
     if (e != hipSuccess) return worker_failed(w, RT_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
-    std::vector<uint32_t> bands = w.mine;
-    std::sort(bands.begin(), bands.end());
     const Plan &plan = job.plan;
     const int first_rank = m->workers[0].rank;
     ncclResult_t r;
     {
         std::lock_guard<std::mutex> lock(g_rccl_mutex);
         r = g_rccl.GroupStart();
-        for (size_t k = 0; k < bands.size() && r == kNcclSuccess;) {
-            size_t j = k + 1;
-            while (j < bands.size() && bands[j] == bands[j - 1] + 1) ++j;
-            const size_t off = (size_t)bands[k] * plan.band_rows * plan.row_bytes;
-            const size_t end = std::min<size_t>(frame_bytes, (size_t)(bands[j - 1] + 1) * plan.band_rows * plan.row_bytes);
-            r = g_rccl.Send(w.d_buf + off, end - off, kNcclUint8, first_rank, m->comms[(size_t)w.rank], w.slot[0].stream);
-            if (r == kNcclSuccess) r = g_rccl.Recv(job.frame_device + off, end - off, kNcclUint8, w.rank, m->comms[(size_t)first_rank], w.recv);
-            k = j;
+        for (size_t k = 0; k < w.mine.size() && r == kNcclSuccess; ++k) {
+            const uint32_t u = w.mine[k];
+            const size_t off = plan.unit_off[u], bytes = (size_t)plan.unit_rows[u] * plan.row_bytes;
+            if (!bytes) continue;
+            r = g_rccl.Send(w.d_buf + off, bytes, kNcclUint8, first_rank, m->comms[(size_t)w.rank], w.slot[0].stream);
+            if (r == kNcclSuccess) r = g_rccl.Recv(m->stage0 + off, bytes, kNcclUint8, w.rank, m->comms[(size_t)first_rank], w.recv);
         }
         const ncclResult_t r_end = g_rccl.GroupEnd();
         if (r == kNcclSuccess) r = r_end;
     }
-    if (r != kNcclSuccess) return worker_failed(w, RT_ERR_HIP, std::string("collecting the bands with RCCL: ") + g_rccl.GetErrorString(r));
-    e = hipStreamSynchronize(w.slot[0].stream);
+    if (r != kNcclSuccess) return worker_failed(w, RT_ERR_HIP, std::string("collecting the units with RCCL: ") + g_rccl.GetErrorString(r));
+    for (size_t k = 0; k < w.mine.size() && e == hipSuccess; ++k) e = place_unit(m, job, w.mine[k], w.recv);
+    if (e == hipSuccess) e = hipStreamSynchronize(w.slot[0].stream);
     if (e == hipSuccess) {
         DeviceScope first(m->workers[0].device);
         e = hipStreamSynchronize(w.recv);
     }
-    if (e != hipSuccess) worker_failed(w, RT_ERR_HIP, std::string("waiting for the collected bands: ") + hipGetErrorString(e));
+    if (e != hipSuccess) worker_failed(w, RT_ERR_HIP, std::string("waiting for the collected units: ") + hipGetErrorString(e));
 }
 
-// One worker's part of a call: takes bands from the cursor while its GPU has fewer than two in flight.
+// One worker's part of a call: takes units from the cursor while its GPU has fewer than two in flight.
 void run_worker(rt_multi *m, Worker &w) {
     const Job &job = m->job;
     const Plan &plan = job.plan;
@@ -315,27 +350,25 @@ void run_worker(rt_multi *m, Worker &w) {
     w.rendered_ms = w.finished_ms = 0.0;
     w.slot[0].band = w.slot[1].band = UINT32_MAX;
     if (hipSetDevice(w.device) != hipSuccess) return worker_failed(w, RT_ERR_HIP, "hipSetDevice failed");
-    const size_t frame_bytes = (size_t)camera.vsize * plan.row_bytes;
-    const bool straight = job.frame_on_first && w.on_first;     // renders into the frame itself
-    const bool collect = job.frame_device && !w.on_first;       // its bands travel to devices[0]
-    char *base = straight ? job.frame_on_first : w.d_buf;
-    auto band_bytes = [&](uint32_t b) {
-        const uint32_t y0 = b * plan.band_rows, y1 = std::min(camera.vsize, y0 + plan.band_rows);
-        return (size_t)(y1 - y0) * plan.row_bytes;
-    };
+    const bool straight = job.frame_device && w.on_first;   // renders its stripes into the frame itself
+    const bool collect = job.frame_device && !w.on_first;   // its packed units travel to devices[0]
     if (plan.stats)
         for (Slot &s : w.slot)
             if (rt::capi_counters_reset(s.scene, s.stream) != RT_OK) return worker_failed(w, RT_ERR_HIP, rt_last_error());
-    auto retire = [&](Slot &s) {  // waits for the band in flight in `s` and delivers it
+    auto retire = [&](Slot &s) {  // waits for the unit in flight in `s` and delivers it
         if (s.band == UINT32_MAX) return true;
         const hipError_t e = hipEventSynchronize(s.done);
         if (e != hipSuccess) {
             worker_failed(w, RT_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
             return false;
         }
-        if (job.rgb) {
-            const size_t off = (size_t)s.band * plan.band_rows * plan.row_bytes;
-            std::memcpy(job.rgb + off, job.stage + off, band_bytes(s.band));
+        if (job.rgb) {  // staged packed unit -> its stripes of the caller's frame
+            const char *from = job.stage + plan.unit_off[s.band];
+            for (uint32_t st = s.band; st < plan.n_stripes; st += plan.n_units) {
+                const uint32_t y0 = st * plan.band_rows, y1 = std::min(camera.vsize, y0 + plan.band_rows);
+                std::memcpy(job.rgb + (size_t)y0 * plan.row_bytes, from, (size_t)(y1 - y0) * plan.row_bytes);
+                from += (size_t)(y1 - y0) * plan.row_bytes;
+            }
         }
         s.band = UINT32_MAX;
         return true;
@@ -343,43 +376,54 @@ void run_worker(rt_multi *m, Worker &w) {
     for (int k = 0;; k ^= 1) {
         Slot &s = w.slot[k];
         if (!retire(s)) break;
-        const uint32_t b = m->cursor.fetch_add(1);
-        if (b >= plan.n_bands) break;
+        const uint32_t u = m->cursor.fetch_add(1);
+        if (u >= plan.n_units) break;
         rt_render_opts o;
         std::memset(&o, 0, sizeof o);
-        o.row_begin = b * plan.band_rows;
-        o.row_end = std::min(camera.vsize, o.row_begin + plan.band_rows);
+        o.band_rows = plan.band_rows;
+        o.band_first = u;
+        o.band_step = plan.n_units;
         o.max_depth = plan.max_depth;
-        o.flags = plan.flags;
+        o.flags = plan.flags | (straight ? RT_RENDER_IN_PLACE : 0u);
         o.stream = s.stream;
-        const size_t off = (size_t)o.row_begin * plan.row_bytes;
-        double *target = reinterpret_cast<double *>(base + off);
+        const size_t off = plan.unit_off[u], bytes = (size_t)plan.unit_rows[u] * plan.row_bytes;
+        double *target = reinterpret_cast<double *>(straight ? job.frame_device : w.d_buf + off);
         const int rc = plan.stats ? rt::capi_render_device_counting(s.scene, &camera, &o, target) : rt_render_device(s.scene, &camera, &o, target, nullptr);
         if (rc != RT_OK) {
             worker_failed(w, rc, rt_last_error());
             break;
         }
         hipError_t e = hipEventRecord(s.rendered, s.stream);
-        if (e == hipSuccess && job.stage) e = hipMemcpyAsync(job.stage + off, base + off, band_bytes(b), hipMemcpyDeviceToHost, s.stream);
-        else if (e == hipSuccess && collect && m->gather == RT_GATHER_COPY)
-            e = hipMemcpyPeerAsync(job.frame_device + off, m->workers[0].device, base + off, w.device, band_bytes(b), s.stream);
+        if (e == hipSuccess && job.stage && bytes) e = hipMemcpyAsync(job.stage + off, w.d_buf + off, bytes, hipMemcpyDeviceToHost, s.stream);
+        else if (e == hipSuccess && collect && m->gather == RT_GATHER_COPY && bytes)
+            e = hipMemcpyPeerAsync(m->stage0 + off, m->workers[0].device, w.d_buf + off, w.device, bytes, s.stream);
         if (e == hipSuccess) e = hipEventRecord(s.done, s.stream);
+        if (e == hipSuccess && collect && m->gather == RT_GATHER_COPY) {
+            // on devices[0], behind the copy: the unit's stripes to their rows of the frame
+            DeviceScope first(m->workers[0].device);
+            e = hipStreamWaitEvent(w.recv, s.done, 0);
+            if (e == hipSuccess) e = place_unit(m, job, u, w.recv);
+        }
         if (e != hipSuccess) {
-            worker_failed(w, RT_ERR_HIP, std::string("queueing a band: ") + hipGetErrorString(e));
+            worker_failed(w, RT_ERR_HIP, std::string("queueing a unit: ") + hipGetErrorString(e));
             break;
         }
-        s.band = b;
-        w.mine.push_back(b);
+        s.band = u;
+        w.mine.push_back(u);
     }
     // the kernels of this GPU have finished when both slots' `rendered` events have
     for (Slot &s : w.slot)
         if (s.band != UINT32_MAX && hipEventSynchronize(s.rendered) != hipSuccess) worker_failed(w, RT_ERR_HIP, "hipEventSynchronize failed");
     w.rendered_ms = ms_since(job.t0);
-    if (w.rc == RT_OK && collect && m->gather == RT_GATHER_RCCL) collect_with_rccl(m, w, job, frame_bytes);
+    if (w.rc == RT_OK && collect && m->gather == RT_GATHER_RCCL) collect_with_rccl(m, w, job);
     (void)retire(w.slot[0]);
     (void)retire(w.slot[1]);
     for (Slot &s : w.slot)
         if (hipStreamSynchronize(s.stream) != hipSuccess) worker_failed(w, RT_ERR_HIP, "hipStreamSynchronize failed");
+    if (collect && m->gather == RT_GATHER_COPY) {
+        DeviceScope first(m->workers[0].device);
+        if (hipStreamSynchronize(w.recv) != hipSuccess) worker_failed(w, RT_ERR_HIP, "hipStreamSynchronize failed (placement)");
+    }
     if (plan.stats && w.rc == RT_OK)
         for (Slot &s : w.slot) {
             rt_stats st;
@@ -489,6 +533,9 @@ int rt_multi_create(const rt_world_desc *world, const int *devices, uint32_t n_d
         if (devices[k] < 0 || devices[k] >= visible) return rt::capi_set_error(RT_ERR_NO_DEVICE, "device ordinal " + std::to_string(devices[k]) + " out of range");
     std::unique_ptr<rt_multi, void (*)(rt_multi *)> m(new rt_multi, rt_multi_destroy);
     m->workers.resize(n_devices);
+    // Test aid: treat every worker but the first as if it sat on another GPU (own buffer, peer copy into the staging
+    // memory, placement), so that the whole collection by copies can be exercised on a box with a single GPU.
+    if (const char *t = getenv("RT_MULTI_TEST_PEERS")) m->test_peers = t[0] == '1';
     for (uint32_t k = 0; k < n_devices; ++k) {
         Worker &w = m->workers[k];
         w.device = devices[k];
@@ -498,7 +545,7 @@ int rt_multi_create(const rt_world_desc *world, const int *devices, uint32_t n_d
             it = m->distinct.end() - 1;
         }
         w.rank = (int)(it - m->distinct.begin());
-        w.on_first = w.device == devices[0];
+        w.on_first = w.device == devices[0] && !(m->test_peers && k > 0);
         for (Slot &s : w.slot) {
             int rc = rt_scene_create(world, w.device, &s.scene);
             if (rc != RT_OK) return rc;
@@ -514,6 +561,7 @@ int rt_multi_create(const rt_world_desc *world, const int *devices, uint32_t n_d
             if (e != hipSuccess) return fail_hip(e, "creating a worker's receiving stream");
         }
     }
+    if (m->distinct.size() == 1 && m->test_peers && n_devices > 1) m->gather = RT_GATHER_COPY;
     if (m->distinct.size() > 1) {
         enable_peer_access(m->distinct);
         m->gather = RT_GATHER_COPY;
@@ -576,6 +624,10 @@ void rt_multi_destroy(rt_multi *m) {
         }
     }
     if (m->h_stage) (void)hipHostFree(m->h_stage);
+    if (m->stage0 && !m->workers.empty()) {
+        DeviceScope scope(m->workers[0].device);
+        (void)hipFree(m->stage0);
+    }
     delete m;
 }
 
@@ -587,7 +639,7 @@ int rt_multi_get_info(const rt_multi *m, rt_multi_info *out) {
     out->gather = m->gather;
     out->rccl_ranks = (uint32_t)m->comms.size();
     out->band_rows = m->last_plan.band_rows;
-    out->n_bands = m->last_plan.n_bands;
+    out->n_units = m->last_plan.n_units;
     std::snprintf(out->note, sizeof out->note, "%s", m->gather == RT_GATHER_RCCL ? g_rccl.path.c_str() : m->gather_note.c_str());
     return RT_OK;
 }
@@ -599,17 +651,27 @@ int rt_multi_render_device(rt_multi *m, const rt_camera_desc *camera, const rt_r
     if (!frame_device) return rt::capi_set_error(RT_ERR_INVALID_ARGUMENT, "frame_device must not be NULL");
     if (plan.stats && !stats) return rt::capi_set_error(RT_ERR_INVALID_ARGUMENT, "collect_stats needs a stats pointer");
     if (stats) std::memset(stats, 0, sizeof *stats);
-    const size_t frame_bytes = (size_t)camera->vsize * plan.row_bytes;
+    const size_t packed_bytes = plan.unit_off[plan.n_units];
+    bool peers = false;
     for (Worker &w : m->workers)
         if (!w.on_first) {
             DeviceScope scope(w.device);
-            hipError_t e = grow_device(w, frame_bytes);
-            if (e != hipSuccess) return fail_hip(e, "allocating a GPU's band buffer");
+            hipError_t e = grow_device(w, packed_bytes);
+            if (e != hipSuccess) return fail_hip(e, "allocating a GPU's buffer of packed units");
+            peers = true;
         }
+    if (peers && packed_bytes > m->stage0_cap) {
+        DeviceScope scope(m->workers[0].device);
+        if (m->stage0) (void)hipFree(m->stage0);
+        m->stage0 = nullptr;
+        m->stage0_cap = 0;
+        hipError_t e = hipMalloc((void **)&m->stage0, packed_bytes);
+        if (e != hipSuccess) return fail_hip(e, "allocating the staging memory for other GPUs' units");
+        m->stage0_cap = packed_bytes;
+    }
     m->job = Job{};
     m->job.camera = *camera;
     m->job.plan = plan;
-    m->job.frame_on_first = static_cast<char *>(frame_device);
     m->job.frame_device = static_cast<char *>(frame_device);
     return run_all(m, stats);
 }
@@ -621,20 +683,20 @@ int rt_multi_render(rt_multi *m, const rt_camera_desc *camera, const rt_render_o
     if (!rgb) return rt::capi_set_error(RT_ERR_INVALID_ARGUMENT, "rgb must not be NULL");
     if (plan.stats && !stats) return rt::capi_set_error(RT_ERR_INVALID_ARGUMENT, "collect_stats needs a stats pointer");
     if (stats) std::memset(stats, 0, sizeof *stats);
-    const size_t frame_bytes = (size_t)camera->vsize * plan.row_bytes;
-    // Every GPU sends its bands to the host over its own PCIe link: nothing travels between GPUs for a host frame.
+    const size_t packed_bytes = plan.unit_off[plan.n_units];
+    // Every GPU sends its units to the host over its own PCIe link: nothing travels between GPUs for a host frame.
     for (Worker &w : m->workers) {
         DeviceScope scope(w.device);
-        hipError_t e = grow_device(w, frame_bytes);
-        if (e != hipSuccess) return fail_hip(e, "allocating a GPU's band buffer");
+        hipError_t e = grow_device(w, packed_bytes);
+        if (e != hipSuccess) return fail_hip(e, "allocating a GPU's buffer of packed units");
     }
-    if (frame_bytes > m->h_cap) {
+    if (packed_bytes > m->h_cap) {
         if (m->h_stage) (void)hipHostFree(m->h_stage);
         m->h_stage = nullptr;
         m->h_cap = 0;
-        hipError_t e = hipHostMalloc((void **)&m->h_stage, frame_bytes, hipHostMallocPortable);
+        hipError_t e = hipHostMalloc((void **)&m->h_stage, packed_bytes, hipHostMallocPortable);
         if (e != hipSuccess) return fail_hip(e, "allocating pinned staging memory");
-        m->h_cap = frame_bytes;
+        m->h_cap = packed_bytes;
     }
     m->job = Job{};
     m->job.camera = *camera;
@@ -644,7 +706,7 @@ int rt_multi_render(rt_multi *m, const rt_camera_desc *camera, const rt_render_o
     return run_all(m, stats);
 }
 
-int rt_multi_bands_taken(const rt_multi *m, uint32_t *per_worker, uint32_t n) {
+int rt_multi_units_taken(const rt_multi *m, uint32_t *per_worker, uint32_t n) {
     if (!m || (!per_worker && n)) return rt::capi_set_error(RT_ERR_INVALID_ARGUMENT, "NULL argument");
     for (uint32_t k = 0; k < n; ++k) per_worker[k] = k < m->last_taken.size() ? m->last_taken[k] : 0u;
     return RT_OK;

@@ -58,7 +58,7 @@ def test_bench_drives_several_workers_without_a_launcher(gpu):
     assert line["workers"] == 2 and line["n_gpus"] == 1 and line["devices"] == [0, 0]
     assert line["config"]["path"] == "single process, rt_multi_render_device"
     assert line["gather"] == "none" and line["rccl_ranks"] == 0
-    assert sum(line["bands_taken"]) == line["bands"] >= 2 and len(line["bands_taken"]) == 2
+    assert sum(line["units_taken"]) == line["units"] >= 2 and len(line["units_taken"]) == 2
     assert line["value"] > 0 and line["config"]["rays_per_frame"] > 1920 * 1080 and line["gather_ms"] >= 0.0
     assert line["render_ms"] > 0.0 and len(line["worker_render_ms"]) == 2
 
@@ -87,28 +87,93 @@ def test_several_workers_at_the_benchmark_frame_size(gpu, rt, orc, name):
     buf = ctypes.c_void_p()
     assert hip.hipMalloc(ctypes.byref(buf), full.nbytes + 64) == 0
     try:
-        for devices, band_rows in (([0, 0], 0), ([0, 0, 0], 200), ([0], 0)):
+        for devices, band_rows, units in (([0, 0], 0, 0), ([0, 0, 0], 200, 7), ([0], 0, 0)):
             multi = world.multi_scene(devices)
             assert hip.hipMemset(buf, 0xA5, full.nbytes + 64) == 0
-            st = multi.render_device(cam, buf.value, band_rows=band_rows, stats=True)
+            st = multi.render_device(cam, buf.value, band_rows=band_rows, stats=True, units=units)
             got = _device_frame(hip, buf, full.nbytes + 64, np.uint8, (-1,))
             assert np.array_equal(got[:full.nbytes].view(np.float64).reshape(full.shape), full), (devices, band_rows)
             assert (got[full.nbytes:] == 0xA5).all(), "wrote past the frame"
             assert st.as_dict() == st_full.as_dict()
             info = multi.info()
-            assert sum(multi.bands_taken()) == info["n_bands"]
-            if len(devices) == 2:  # the default plan: bands of at least 8 192 tiles, about four per worker
-                assert info["band_rows"] % 8 == 0 and info["band_rows"] // 8 * 480 >= 8192 and 4 <= info["n_bands"] <= 8
+            assert sum(multi.units_taken()) == info["n_units"]
+            if len(devices) == 2:  # the default plan: 16-row stripes dealt to two units per worker
+                assert (info["band_rows"], info["n_units"]) == (16, 4)
             if len(devices) == 1:
-                assert info["n_bands"] == 1
-            multi.render_device(cam, buf.value, band_rows=band_rows, quantized=True)
+                assert info["n_units"] == 1
+            multi.render_device(cam, buf.value, band_rows=band_rows, quantized=True, units=units)
             assert np.array_equal(_device_frame(hip, buf, w * h * 3, np.uint8, (h, w, 3)), q_full)
-            host, st = multi.render(cam, band_rows=band_rows)
+            host, st = multi.render(cam, band_rows=band_rows, units=units)
             assert np.array_equal(host, full)
             del host
             multi.close()
     finally:
         hip.hipFree(buf)
+
+
+def test_collection_by_copies_rehearsed_on_one_gpu(gpu, rt, orc, monkeypatch):
+    """RT_MULTI_TEST_PEERS=1 makes every worker but the first behave as if it sat on another GPU: it renders its units
+    packed into a buffer of its own, copies each behind its kernel (hipMemcpyPeerAsync) into the staging memory of
+    devices[0], and the placement kernel there puts the stripes into the frame.  That is the whole RT_GATHER_COPY path,
+    and on a second GPU only the copy's route differs.  Frames bit-identical to the single-device frame, odd sizes
+    (short last stripe, widths that leave stripes 16-, 4- and 1-byte aligned) included."""
+    hip = _hip()
+    monkeypatch.setenv("RT_MULTI_TEST_PEERS", "1")
+    for name, (w, h), band_rows, units in (("chapter_11", (1920, 1080), 0, 0), ("chapter_14", (403, 301), 8, 5), ("chapter_11", (250, 131), 16, 3),
+                                            ("chapter_6", (64, 64), 0, 0)):
+        sf = rt.SceneFile.from_file(scene_path(name))
+        cam, world = sf.build_camera(w, h), sf.build_world()
+        full, st_full = world.scene().render(cam, stats=True)
+        buf = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(buf), full.nbytes + 64) == 0
+        try:
+            for devices in ([0, 0], [0, 0, 0]):
+                multi = world.multi_scene(devices)
+                assert multi.info()["gather"] == "copy"
+                for quantized in (False, True):
+                    assert hip.hipMemset(buf, 0xA5, full.nbytes + 64) == 0
+                    st = multi.render_device(cam, buf.value, band_rows=band_rows, stats=not quantized, quantized=quantized, units=units)
+                    got = _device_frame(hip, buf, full.nbytes + 64, np.uint8, (-1,))
+                    if quantized:
+                        assert np.array_equal(got[:w * h * 3].reshape(h, w, 3), orc.quantize(full)), (name, devices)
+                        assert (got[w * h * 3:] == 0xA5).all(), "wrote past the 8-bit frame"
+                    else:
+                        assert np.array_equal(got[:full.nbytes].view(np.float64).reshape(full.shape), full), (name, devices)
+                        assert (got[full.nbytes:] == 0xA5).all(), "wrote past the frame"
+                        assert st.as_dict() == st_full.as_dict()
+                    assert sum(multi.units_taken()) == multi.info()["n_units"]
+                multi.close()
+        finally:
+            hip.hipFree(buf)
+
+
+def test_rows_rendered_in_place(gpu, rt, orc):
+    """RT_RENDER_IN_PLACE: a row range, and a selection of bands, stored at their own rows of a whole frame instead of
+    packed; the rest of the frame is left alone."""
+    hip = _hip()
+    for name, (w, h) in (("chapter_11", (403, 301)), ("chapter_14", (320, 203))):
+        sf = rt.SceneFile.from_file(scene_path(name))
+        cam, world = sf.build_camera(w, h), sf.build_world()
+        scene = world.scene()
+        full, _ = scene.render(cam)
+        buf = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(buf), full.nbytes) == 0
+        try:
+            for quantized in (False, True):
+                nbytes = w * h * 3 if quantized else full.nbytes
+                want = orc.quantize(full) if quantized else full
+                dtype = np.uint8 if quantized else np.float64
+                assert hip.hipMemset(buf, 0, nbytes) == 0
+                scene.render_device(cam, buf.value, (40, 96), None, 0, False, False, quantized, in_place=True)
+                assert hip.hipDeviceSynchronize() == 0
+                got = _device_frame(hip, buf, nbytes, dtype, (h, w, 3))
+                assert np.array_equal(got[40:96], want[40:96]) and not got[:40].any() and not got[96:].any()
+                for first in (0, 1, 2):  # three calls complete the frame
+                    scene.render_device_bands(cam, buf.value, 24, first, 3, None, 0, False, False, quantized, in_place=True)
+                assert hip.hipDeviceSynchronize() == 0
+                assert np.array_equal(_device_frame(hip, buf, nbytes, dtype, (h, w, 3)), want)
+        finally:
+            hip.hipFree(buf)
 
 
 def test_one_worker_costs_what_the_single_device_call_costs(gpu, rt):
@@ -162,7 +227,7 @@ def test_frame_assembled_across_two_gpus(gpu, rt, orc, gather, monkeypatch):
         assert hip.hipSetDevice(0) == 0
         assert hip.hipMalloc(ctypes.byref(buf), full.nbytes) == 0
         try:
-            for devices, band_rows in (([0, 1], 0), ([0, 1, 1], 64), ([1, 0], 128)):
+            for devices, band_rows in (([0, 1], 0), ([0, 1, 1], 64), ([1, 0], 128)):  # band_rows: the stripe height
                 multi = world.multi_scene(devices)
                 info = multi.info()
                 assert info["gather"] == gather and info["n_devices"] == 2 and info["rccl_ranks"] == (2 if gather == "rccl" else 0)
@@ -177,7 +242,7 @@ def test_frame_assembled_across_two_gpus(gpu, rt, orc, gather, monkeypatch):
                     else:
                         assert np.array_equal(_device_frame(hip, frame, full.nbytes, np.float64, full.shape), full), (name, devices)
                         assert st.as_dict() == st_full.as_dict()
-                    assert sum(multi.bands_taken()) == multi.info()["n_bands"]
+                    assert sum(multi.units_taken()) == multi.info()["n_units"]
                 host, _ = multi.render(cam, band_rows=band_rows)
                 assert np.array_equal(host, full)
                 hip.hipFree(frame)

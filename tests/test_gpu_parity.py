@@ -1015,29 +1015,31 @@ def test_several_workers_share_one_frame(gpu, rt, orc):
         buf = ctypes.c_void_p()
         assert hip.hipMalloc(ctypes.byref(buf), full.nbytes + 64) == 0
         try:
-            for devices, band_rows in (([0, 0], 0), ([0, 0, 0], 8), ([0], 24), ([0, 0], 1000)):
+            for devices, band_rows, units in (([0, 0], 0, 0), ([0, 0, 0], 8, 5), ([0], 24, 0), ([0, 0], 1000, 0), ([0, 0], 16, 400)):
                 multi = world.multi_scene(devices)
                 # frame in device memory, f64
                 assert hip.hipMemset(buf, 0xA5, full.nbytes + 64) == 0
-                st = multi.render_device(cam, buf.value, band_rows=band_rows, stats=True)
+                st = multi.render_device(cam, buf.value, band_rows=band_rows, stats=True, units=units)
                 got = np.zeros(full.nbytes + 64, dtype=np.uint8)
                 assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), buf, got.nbytes, 2) == 0
                 assert np.array_equal(got[:full.nbytes].view(np.float64).reshape(full.shape), full), (name, devices, band_rows)
                 assert (got[full.nbytes:] == 0xA5).all(), "wrote past the frame"
                 assert st.as_dict() == st_full.as_dict()
                 info = multi.info()
-                # no band height named: one worker takes the frame whole, several cut it -- but not below 8 192 tiles a band
-                assert info["band_rows"] == (band_rows or (h + 7) // 8 * 8) and info["n_bands"] == (h + info["band_rows"] - 1) // info["band_rows"]
+                # no stripe height named: 16 rows (one worker alone: the frame as one launch); units never outnumber stripes
+                stripes = (h + info["band_rows"] - 1) // info["band_rows"]
+                assert info["band_rows"] == (band_rows or ((h + 7) // 8 * 8 if len(devices) == 1 else 16))
+                assert info["n_units"] == (min(units, stripes) if units else 1 if len(devices) == 1 else info["n_units"]) and 1 <= info["n_units"] <= stripes
                 assert (info["n_workers"], info["n_devices"], info["gather"], info["rccl_ranks"]) == (len(devices), 1, "none", 0)
-                assert sum(multi.bands_taken()) == info["n_bands"] and len(multi.bands_taken()) == len(devices)
+                assert sum(multi.units_taken()) == info["n_units"] and len(multi.units_taken()) == len(devices)
                 assert st.kernel_ms > 0.0 and st.gather_ms >= 0.0 and max(multi.worker_ms()) > 0.0
                 # 8-bit frame
-                st = multi.render_device(cam, buf.value, band_rows=band_rows, quantized=True)
+                st = multi.render_device(cam, buf.value, band_rows=band_rows, quantized=True, units=units)
                 q = np.zeros(w * h * 3, dtype=np.uint8)
                 assert hip.hipMemcpy(q.ctypes.data_as(ctypes.c_void_p), buf, q.nbytes, 2) == 0
                 assert np.array_equal(q.reshape(h, w, 3), orc.quantize(full))
                 # frame in host memory
-                host, st = multi.render(cam, band_rows=band_rows, stats=True)
+                host, st = multi.render(cam, band_rows=band_rows, stats=True, units=units)
                 assert np.array_equal(host, full) and st.rays == st_full.rays
                 multi.close()
         finally:
