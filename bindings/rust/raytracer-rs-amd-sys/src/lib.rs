@@ -227,6 +227,8 @@ extern "C" {
 
     pub fn rt_canvas_to_ppm(rgb: *const f64, width: u32, height: u32, out: *mut c_char, cap: usize) -> usize;
     pub fn rt_canvas_write_ppm(rgb: *const f64, width: u32, height: u32, path: *const c_char) -> c_int;
+    pub fn rt_canvas_to_jpeg(rgb: *const f64, width: u32, height: u32, out: *mut u8, cap: usize) -> usize;
+    pub fn rt_canvas_write_jpeg(rgb: *const f64, width: u32, height: u32, path: *const c_char) -> c_int;
     pub fn rt_canvas_quantize(rgb: *const f64, n: usize, out: *mut u8) -> c_int;
     pub fn rt_canvas_quantize_device(rgb_device: *const f64, n: usize, out_device: *mut u8, stream: *mut c_void) -> c_int;
 

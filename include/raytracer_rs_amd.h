@@ -315,6 +315,13 @@ int rt_view_transform(const double from[3], const double to[3], const double up[
 size_t rt_canvas_to_ppm(const double *rgb, uint32_t width, uint32_t height, char *out, size_t cap);
 /* Canvas::to_ppm (rendering/canvas.rs:116-120). */
 int rt_canvas_write_ppm(const double *rgb, uint32_t width, uint32_t height, const char *path);
+/* Canvas::to_rgb_image + the encoder behind Canvas::to_jpeg (rendering/canvas.rs:92-114: `image` 0.24.6,
+ * ImageOutputFormat::Jpeg(100)): the bytes of the JPEG file into `out` (capacity cap); returns the length needed (0
+ * for an empty frame or one beyond 65535 pixels a side), so a first call with out = NULL sizes the buffer.  Baseline,
+ * quality 100, no chroma subsampling; byte-identical to the files the reference ships beside its PPMs. */
+size_t rt_canvas_to_jpeg(const double *rgb, uint32_t width, uint32_t height, unsigned char *out, size_t cap);
+/* Canvas::to_jpeg (rendering/canvas.rs:109-114). */
+int rt_canvas_write_jpeg(const double *rgb, uint32_t width, uint32_t height, const char *path);
 /* convert_canvas_color_value_to_decimal_rgb_value (rendering/canvas.rs:123-130) over n values. */
 int rt_canvas_quantize(const double *rgb, size_t n, uint8_t *out);
 /* The same over a frame still in device memory (both pointers are device pointers on the current device),

@@ -144,6 +144,8 @@ SIGNATURES = {
     "rt_view_transform": (C.c_int, [_P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "rt_canvas_to_ppm": (C.c_size_t, [_P(C.c_double), C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]),
     "rt_canvas_write_ppm": (C.c_int, [_P(C.c_double), C.c_uint32, C.c_uint32, C.c_char_p]),
+    "rt_canvas_to_jpeg": (C.c_size_t, [_P(C.c_double), C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]),
+    "rt_canvas_write_jpeg": (C.c_int, [_P(C.c_double), C.c_uint32, C.c_uint32, C.c_char_p]),
     "rt_canvas_quantize": (C.c_int, [_P(C.c_double), C.c_size_t, _P(C.c_uint8)]),
     "rt_canvas_quantize_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "rt_scene_file_load": (C.c_int, [C.c_char_p, _P(C.c_void_p)]),

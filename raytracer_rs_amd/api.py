@@ -687,6 +687,17 @@ class Canvas:
         """Canvas::to_ppm (canvas.rs:116-120)"""
         L.check(L.lib().rt_canvas_write_ppm(self._ptr(), self.width, self.height, path.encode()))
 
+    def to_jpeg_bytes(self) -> bytes:
+        """The file Canvas::to_jpeg writes (canvas.rs:92-114: quality 100 through the `image` crate's encoder), in memory."""
+        n = L.lib().rt_canvas_to_jpeg(self._ptr(), self.width, self.height, None, 0)
+        buf = C.create_string_buffer(n)
+        L.lib().rt_canvas_to_jpeg(self._ptr(), self.width, self.height, buf, n)
+        return buf.raw[:n]
+
+    def to_jpeg(self, path: str) -> None:
+        """Canvas::to_jpeg (canvas.rs:109-114)"""
+        L.check(L.lib().rt_canvas_write_jpeg(self._ptr(), self.width, self.height, path.encode()))
+
     def to_rgb8(self) -> np.ndarray:
         """The 8-bit image of canvas.rs:123-130 as uint8 [height, width, 3]."""
         out = np.empty((self.height, self.width, 3), dtype=np.uint8)

@@ -1,15 +1,15 @@
 // rt_render: the command-line face of the library, standing in for the reference's `main` (main.rs:70-184), which
 // loads a scene file, renders it and writes a PPM per chapter.
 //
-//   rt_render <scene.toml> [-o out.ppm] [--width W --height H] [--device D | --devices D0,D1,... [--band-rows R]] [--depth N] [--stats]
+//   rt_render <scene.toml> [-o out.ppm] [--jpeg out.jpg] [--width W --height H] [--device D | --devices D0,D1,... [--band-rows R]] [--depth N] [--stats]
 //   rt_render --all-chapters <scenes_dir> <outputs_dir> [--device D | --devices D0,D1,... [--band-rows R]]
 //
 // --devices renders one frame on several GPUs (rt_multi_render: bands of rows taken from a shared cursor; an ordinal
 // may be listed more than once for several workers on one GPU); --band-rows sets the height of a band (a multiple of
 // 8, the tile height; default: chosen by the library).
 // The second form reproduces main()'s set of scene-file renders: chapter_5 .. chapter_14 into the reference's
-// output names.  (The chapter 2 and 4 plots of main() draw on a canvas directly and never touch the renderer;
-// JPEG output goes through a third-party encoder: neither is provided.)
+// output names, a .ppm and a .jpg each as main() writes them (main.rs:77-169).  (The chapter 2 and 4 plots of main()
+// draw on a canvas directly and never touch the renderer: not provided.)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -33,7 +33,7 @@ struct Options {
     uint32_t band_rows = 0;      // with --devices: rows per band, 0 = the library's choice
 };
 
-int render_file(const std::string &scene_path, const std::string &out_path, const Options &opt) {
+int render_file(const std::string &scene_path, const std::string &out_path, const std::string &jpeg_path, const Options &opt) {
     rt_scene_file *file = nullptr;
     if (rt_scene_file_load(scene_path.c_str(), &file) != RT_OK) return fail(scene_path.c_str());
     rt_camera_desc cam;
@@ -69,6 +69,7 @@ int render_file(const std::string &scene_path, const std::string &out_path, cons
             if (rt_render(scene, &cam, &ro, rgb.data(), &st) != RT_OK) { fail("render"); break; }
         }
         if (rt_canvas_write_ppm(rgb.data(), cam.hsize, cam.vsize, out_path.c_str()) != RT_OK) { fail(out_path.c_str()); break; }
+        if (!jpeg_path.empty() && rt_canvas_write_jpeg(rgb.data(), cam.hsize, cam.vsize, jpeg_path.c_str()) != RT_OK) { fail(jpeg_path.c_str()); break; }
         std::printf("%s -> %s  %ux%u  kernel %.3f ms", scene_path.c_str(), out_path.c_str(), cam.hsize, cam.vsize, st.kernel_ms);
         if (multi) std::printf("  gather %.3f ms", st.gather_ms);
         if (opt.stats)
@@ -89,7 +90,7 @@ int render_file(const std::string &scene_path, const std::string &out_path, cons
 int main(int argc, char **argv) {
     Options opt;
     std::vector<std::string> pos;
-    std::string out;
+    std::string out, jpeg;
     bool all = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -101,6 +102,7 @@ int main(int argc, char **argv) {
             return argv[++i];
         };
         if (a == "-o" || a == "--out") out = value("-o");
+        else if (a == "--jpeg") jpeg = value("--jpeg");
         else if (a == "--width") opt.width = (uint32_t)std::strtoul(value("--width"), nullptr, 10);
         else if (a == "--height") opt.height = (uint32_t)std::strtoul(value("--height"), nullptr, 10);
         else if (a == "--device") opt.device = std::atoi(value("--device"));
@@ -125,7 +127,7 @@ int main(int argc, char **argv) {
     if ((all && pos.size() != 2) || (!all && pos.size() != 1) || (opt.width != 0) != (opt.height != 0) || (opt.band_rows && opt.devices.empty()) ||
         opt.band_rows % 8 != 0) {
         std::fprintf(stderr,
-                     "usage: rt_render <scene.toml> [-o out.ppm] [--width W --height H] [--device D | --devices D0,D1,... [--band-rows R]] [--depth N] [--stats]\n"
+                     "usage: rt_render <scene.toml> [-o out.ppm] [--jpeg out.jpg] [--width W --height H] [--device D | --devices D0,D1,... [--band-rows R]] [--depth N] [--stats]\n"
                      "       rt_render --all-chapters <scenes_dir> <outputs_dir> [--device D | --devices D0,D1,... [--band-rows R]]\n"
                      "       (--band-rows: a multiple of 8, only with --devices)\n");
         return 2;
@@ -137,7 +139,7 @@ int main(int argc, char **argv) {
             if (dot != std::string::npos && out.find('/', dot) == std::string::npos) out.resize(dot);
             out += ".ppm";
         }
-        return render_file(pos[0], out, opt);
+        return render_file(pos[0], out, jpeg, opt);
     }
     // main.rs:70-184: scene file -> output name
     static const char *const chapters[][2] = {
@@ -145,6 +147,6 @@ int main(int argc, char **argv) {
         {"chapter_9", "chapter_9_plane_scene"},  {"chapter_10", "chapter_10_patterns"}, {"chapter_11", "chapter_11_reflections"},
         {"chapter_12", "chapter_12_cubes"},      {"chapter_13", "chapter_13_rocket"},   {"chapter_14", "chapter_14_groups"}};
     int bad = 0;
-    for (const auto &c : chapters) bad += render_file(pos[0] + "/" + c[0] + ".toml", pos[1] + "/" + c[1] + ".ppm", opt);
+    for (const auto &c : chapters) bad += render_file(pos[0] + "/" + c[0] + ".toml", pos[1] + "/" + c[1] + ".ppm", pos[1] + "/" + c[1] + ".jpg", opt);
     return bad ? 1 : 0;
 }

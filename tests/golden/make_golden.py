@@ -12,6 +12,9 @@ What it takes (data only, never source):
     and the SHA-256 of the original P3 text recorded in MANIFEST.json.
   * outputs/chapter_{7_and_8_world,9_plane_scene,12_cubes,14_groups}.jpg -- the only reference renderings of those
     scenes (their PPMs are not in the checkout).  JPEG quality 100: a loose oracle, copied byte for byte.
+  * outputs/chapter_{5_circle,6_sphere,10_patterns,11_reflections,13_rocket}.jpg -- the JPEG the reference wrote of
+    the same canvas as each of those PPMs (Canvas::to_jpeg, quality 100): together with the PPM's pixels they pin the
+    JPEG writer bit for bit.  Copied byte for byte.
   * scenes/*.toml -- the scene inputs, copied byte for byte.
 """
 import hashlib
@@ -39,7 +42,7 @@ def parse_p3(text: bytes):
 
 def main() -> None:
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
-    manifest = {"ppm": {}, "jpg": {}, "scenes": {}}
+    manifest = {"ppm": {}, "jpg": {}, "jpg_of_ppm": {}, "scenes": {}}
     for name in PPMS:
         with open(os.path.join(ref, "outputs", name + ".ppm"), "rb") as f:
             text = f.read()
@@ -59,6 +62,11 @@ def main() -> None:
         shutil.copyfile(src, os.path.join(HERE, name + ".jpg"))
         with open(src, "rb") as f:
             manifest["jpg"][name] = {"sha256": hashlib.sha256(f.read()).hexdigest()}
+    for name in PPMS:
+        src = os.path.join(ref, "outputs", name + ".jpg")
+        shutil.copyfile(src, os.path.join(HERE, name + ".jpg"))
+        with open(src, "rb") as f:
+            manifest["jpg_of_ppm"][name] = {"sha256": hashlib.sha256(f.read()).hexdigest()}
     os.makedirs(os.path.join(HERE, "scenes"), exist_ok=True)
     for fn in sorted(os.listdir(os.path.join(ref, "scenes"))):
         if fn.endswith(".toml"):

@@ -100,7 +100,10 @@ def test_command_line_renderer_writes_the_reference_ppm(gpu, tmp_path):
 
 def test_command_line_renderer_reproduces_mains_set_of_images(gpu, tmp_path):
     """`rt_render --all-chapters` stands in for the reference's main() (main.rs:172-184): nine scene files in, nine PPMs
-    under the reference's output names out; the five whose PPM the reference ships are byte-identical to it."""
+    and nine JPEGs under the reference's output names out; the five whose PPM the reference ships are byte-identical
+    to it, and so are their JPEGs (Canvas::to_jpeg, canvas.rs:109-114); the other four JPEGs are held to the
+    reference's JPEGs of those scenes pixel by pixel after decoding (both are quality-100 encodings of frames that
+    agree to the last bit wherever they can be compared, so they agree almost everywhere exactly)."""
     import hashlib
     import json
     import subprocess
@@ -109,7 +112,8 @@ def test_command_line_renderer_reproduces_mains_set_of_images(gpu, tmp_path):
     done = subprocess.run([exe, "--all-chapters", os.path.join(GOLDEN, "scenes"), str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert done.returncode == 0, done.stderr
     with open(os.path.join(GOLDEN, "MANIFEST.json")) as f:
-        ppm = json.load(f)["ppm"]
+        manifest = json.load(f)
+    ppm, jpg_of_ppm = manifest["ppm"], manifest["jpg_of_ppm"]
     names = ["chapter_5_circle", "chapter_6_sphere", "chapter_7_and_8_world", "chapter_9_plane_scene", "chapter_10_patterns",
              "chapter_11_reflections", "chapter_12_cubes", "chapter_13_rocket", "chapter_14_groups"]
     for name in names:
@@ -117,6 +121,14 @@ def test_command_line_renderer_reproduces_mains_set_of_images(gpu, tmp_path):
         assert data.startswith(b"P3\n") and data.endswith(b"\n\n")
         if name in ppm:
             assert hashlib.sha256(data).hexdigest() == ppm[name]["sha256_p3_text"], name
+        jpeg = (tmp_path / (name + ".jpg")).read_bytes()
+        if name in jpg_of_ppm:
+            assert hashlib.sha256(jpeg).hexdigest() == jpg_of_ppm[name]["sha256"], name
+        else:  # the reference's own JPEG of this scene is the only rendering of it the reference ships
+            with open(os.path.join(GOLDEN, name + ".jpg"), "rb") as f:
+                theirs = f.read()
+            assert hashlib.sha256(theirs).hexdigest() == manifest["jpg"][name]["sha256"]
+            assert jpeg == theirs, f"{name}.jpg differs from the reference's file"
     assert sum(name in ppm for name in names) == 5
 
 
