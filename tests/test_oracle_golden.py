@@ -2,8 +2,11 @@
 
 Bit-level: the five scenes whose P3 files are in the reference checkout -- every 8-bit value of every pixel, and the
 SHA-256 of the regenerated P3 text against the SHA-256 of the reference's own file.
-Loose: the four scenes the reference checkout only holds as JPEG (quality 100); a correct reading of groups, bounds,
-material inheritance, cubes and planes lands within JPEG noise of them, a wrong one does not.
+The four scenes the reference checkout only holds as JPEG (quality 100): loosely, pixel by pixel after decoding (a
+correct reading of groups, bounds, material inheritance, cubes and planes lands within JPEG noise of them, a wrong one
+does not) -- and exactly: the oracle's frame, through the restated encoder (oracle/jpeg.py, itself pinned byte for byte
+by the five scenes that have both files), gives the reference's JPEG FILE byte for byte, which it can only do when the
+8-bit pixels are the reference's in all but freak cases.
 """
 import hashlib
 import json
@@ -51,6 +54,18 @@ def test_oracle_close_to_reference_jpeg(orc, scene, image):
     d = np.abs(frame - jpg).max(axis=2)
     assert (d <= 6).mean() >= 0.99, f"only {(d <= 6).mean():.4f} of pixels within 6 levels of the JPEG"
     assert (d <= 16).mean() >= 0.9995, f"{int((d > 16).sum())} pixels beyond 16 levels"
+
+
+@pytest.mark.parametrize("scene,image", JPG_PAIRS)
+def test_oracle_reproduces_reference_jpeg_file(orc, scene, image):
+    from oracle import jpeg
+
+    cam, world = orc.load_scene(scene_path(scene))
+    pixels = orc.quantize(orc.render(cam, world, threads=8))
+    with open(os.path.join(GOLDEN, image + ".jpg"), "rb") as f:
+        theirs = f.read()
+    assert hashlib.sha256(theirs).hexdigest() == manifest()["jpg"][image]["sha256"]
+    assert jpeg.jpeg_bytes(pixels) == theirs
 
 
 def test_ray_counts_of_the_native_frames(orc):
