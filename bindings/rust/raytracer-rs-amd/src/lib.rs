@@ -1,17 +1,25 @@
 //! `Camera::render(&World) -> Canvas` (rendering/camera.rs:56-67 of raytracer-rs) on an MI355X.
 //!
-//! Needs two one-line changes in the reference crate: `#[repr(C)]` on `Color` (core/color.rs), so that
+//! Needs two one-line changes in the reference crate: `#[repr(C)]` on `Color` (core/color.rs:4-9), so that
 //! `Canvas.pixels: Vec<Color>` is the `double[h][w][3]` the library fills, and `pub` access to `Matrix4.data`
-//! (core/matrices.rs:7-9) for `row_major`.  Not compiled in the repository's build image (no Rust toolchain).
+//! (core/matrices.rs:7-9, a private field) for `row_major`.  The reference's package is called `raytracer`
+//! (Cargo.toml:2).  Not compiled in the repository's build image (no Rust toolchain); every item used below was
+//! checked by hand against the reference's declarations: `Camera` fields (rendering/camera.rs:8-16, u32 sizes),
+//! `Canvas::new(u32, u32)` (rendering/canvas.rs:17), `Group::children() -> &[Object]` (geometry/groups.rs:66; the
+//! field itself is private), `Cylinder` / `Cone` `minimum, maximum, closed` (geometry/cylinders.rs:15-23),
+//! `HasMaterial::material()`, `Transformable::transformation()` (rendering/objects.rs:23, 29),
+//! `Object::world_transformation()` (objects.rs:241), `World { objects, light_source: Option<PointLight> }`
+//! (rendering/world.rs:14-17; `PointLight` is `Copy`, scene/lights.rs:4), `Material.pattern: Option<Pattern>`,
+//! `Pattern { transform, kind }` and the struct variants of `PatternKind` (scene/patterns.rs:7-28).
 use std::ffi::CStr;
 
-use raytracer_rs::core::matrices::Matrix4;
-use raytracer_rs::rendering::camera::Camera;
-use raytracer_rs::rendering::canvas::Canvas;
-use raytracer_rs::rendering::objects::{HasMaterial, Object, Transformable};
-use raytracer_rs::rendering::world::World;
-use raytracer_rs::scene::materials::Material;
-use raytracer_rs::scene::patterns::PatternKind;
+use raytracer::core::matrices::Matrix4;
+use raytracer::rendering::camera::Camera;
+use raytracer::rendering::canvas::Canvas;
+use raytracer::rendering::objects::{HasMaterial, Object, Transformable};
+use raytracer::rendering::world::World;
+use raytracer::scene::materials::Material;
+use raytracer::scene::patterns::PatternKind;
 use raytracer_rs_amd_sys as sys;
 
 fn row_major(m: &Matrix4) -> [f64; 16] {
@@ -61,12 +69,12 @@ fn flatten(obj: &Object, out: &mut Vec<sys::rt_object_desc>) {
     match obj {
         Object::Cylinder(c) => { d.minimum = c.minimum; d.maximum = c.maximum; d.closed = c.closed as i32; }
         Object::Cone(c) => { d.minimum = c.minimum; d.maximum = c.maximum; d.closed = c.closed as i32; }
-        Object::Group(g) => { d.n_children = g.children.len() as i32; }
+        Object::Group(g) => { d.n_children = g.children().len() as i32; }
         _ => {}
     }
     out.push(d);
     if let Object::Group(g) = obj {
-        for child in &g.children {
+        for child in g.children() {
             flatten(child, out);
         }
     }
@@ -101,7 +109,7 @@ impl GpuWorld {
         let cam = sys::rt_camera_desc { hsize: camera.hsize, vsize: camera.vsize, field_of_view: camera.field_of_view,
                                         transform: row_major(&camera.transform), pixel_size: camera.pixel_size,
                                         half_width: camera.half_width, half_height: camera.half_height };
-        let mut canvas = Canvas::new(camera.hsize as usize, camera.vsize as usize);
+        let mut canvas = Canvas::new(camera.hsize, camera.vsize);
         let rc = unsafe { sys::rt_render(self.scene, &cam, std::ptr::null(), canvas.pixels.as_mut_ptr() as *mut f64, std::ptr::null_mut()) };
         assert!(rc == sys::RT_OK, "{}", last_error());
         canvas

@@ -112,6 +112,13 @@ static const double COST_LEAF[5] = {25.0, 8.0, 60.0, 70.0, 80.0};    // intersec
 // a = lambda * d^T q d with q the unit-norm symmetric matrix A^T diag(1,-1,1) A (A = linear part of the chain of
 // inverses down to the cone) and lambda > 0.  A node can carry one q: cones whose q's agree (same axis and
 // proportions, any size -- every cone of a typical scene) share it; otherwise `ok` is false and the run gets no node.
+// When may two cones' q's count as one?  Replacing q_k by q_0 moves d^T q d by at most 3 tol |d|^2, and the bound a
+// node tests against (2 EPSILON / lambda_min) leaves EPSILON / lambda_min of room above the values at which the
+// reference takes its shortcut.  q's that are meant to be equal -- same axis and proportions -- differ by rounding
+// only (they have unit norm: 1e-16 or so per entry), so the tolerance can be tiny: 1e-12, and never more than a
+// thousandth of that room (small cones have little: lambda grows with 1 / size^2).
+inline double cone_q_tolerance(double lambda_min) { return std::fmin(1e-12, 1e-3 * 1e-5 / lambda_min); }
+
 struct ConeDirs {
     bool any = false, ok = true;
     double q[6] = {0, 0, 0, 0, 0, 0};  // xx, xy, xz, yy, yz, zz
@@ -170,9 +177,9 @@ struct ConeDirs {
         }
         if (!o.ok) ok = false;
         if (!ok) return;
-        for (int i = 0; i < 6; ++i)
-            if (std::fabs(q[i] - o.q[i]) > 1e-9) ok = false;
         lambda_min = std::fmin(lambda_min, o.lambda_min);
+        for (int i = 0; i < 6; ++i)
+            if (!(std::fabs(q[i] - o.q[i]) <= cone_q_tolerance(lambda_min))) ok = false;
     }
 };
 
@@ -478,8 +485,11 @@ struct Builder {
             if ((n.tag & 0xff) == RT_SKIPBOX && (uint32_t)((n.tag >> RT_NODE_LEVEL_SHIFT) & RT_NODE_LEVEL_MASK) == depth && n.xform == RT_SKIP_CONES) with_q.push_back(i);
         }
         bool agree = with_q.size() > 1;
-        for (size_t k = 1; k < with_q.size() && agree; ++k)
-            for (int c = 0; c < 6; ++c) agree = agree && std::fabs((*nodes)[with_q[k]].inv[c] - (*nodes)[with_q[0]].inv[c]) <= 1e-9;
+        for (size_t k = 1; k < with_q.size() && agree; ++k) {
+            // inv[6] = 2 EPSILON / lambda_min of the node that is to take the first node's q
+            const double tol = cone_q_tolerance(2e-5 / (*nodes)[with_q[k]].inv[6]);
+            for (int c = 0; c < 6; ++c) agree = agree && std::fabs((*nodes)[with_q[k]].inv[c] - (*nodes)[with_q[0]].inv[c]) <= tol;
+        }
         if (agree)
             for (size_t i : with_q) {
                 for (int c = 0; c < 6; ++c) (*nodes)[i].inv[c] = (*nodes)[with_q[0]].inv[c];
@@ -573,7 +583,8 @@ static void add_lookahead(std::vector<RtNode> &table) {
         if (r.xform == RT_SKIP_CONES) {  // R's cones must see the directions X's do (one q per node: rt_flatten's ConeDirs)
             if (x.xform != RT_SKIP_CONES) continue;
             bool same = true;
-            for (int k = 0; k < 6; ++k) same = same && std::fabs(x.inv[k] - r.inv[k]) <= 1e-9;
+            const double tol = cone_q_tolerance(2e-5 / r.inv[6]);  // R is tested with X's q
+            for (int k = 0; k < 6; ++k) same = same && std::fabs(x.inv[k] - r.inv[k]) <= tol;
             if (!same) continue;
             bound = r.inv[6];
         }

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <mutex>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 namespace rt {
@@ -32,7 +33,8 @@ public:
     void run(const std::vector<CopySegment> &segments) {
         size_t total = 0;
         for (const CopySegment &s : segments) total += s.bytes;
-        if (total < (4u << 20) || workers_.empty()) {  // not worth waking anybody
+        // (a process forked after the pool was built has the pool's bookkeeping but none of its threads: it copies alone)
+        if (total < (4u << 20) || workers_.empty() || getpid() != owner_) {  // not worth waking anybody
             for (const CopySegment &s : segments) std::memcpy(s.dst, s.src, s.bytes);
             return;
         }
@@ -55,8 +57,10 @@ public:
 
 private:
     static constexpr size_t SLICE = 1u << 20;
+    pid_t owner_ = 0;  // the process whose threads these are
 
     HostCopyPool() {
+        owner_ = getpid();
         unsigned n = std::thread::hardware_concurrency();
         if (const char *e = std::getenv("RT_COPY_THREADS")) n = (unsigned)std::strtoul(e, nullptr, 10) + 1;
         n = n > 8 ? 8 : n;  // the caller's thread is one of them

@@ -718,6 +718,43 @@ def test_cone_linear_shortcut_survives_range_skipping(gpu, rt, orc):
     rays = np.array(rays)
     assert sum(ow.hit(orc.ray(r[:3], r[3:])) is not None for r in rays) >= 10
     _lone_rays_agree(orc, w.scene(), ow, rays)
+    # Small cones (scale 0.03: the room between the reference's threshold and a node's bound shrinks with size^2) whose
+    # axes differ by a few 1e-10 rad, in a group: their direction forms agree to within 1e-9 but not to within rounding,
+    # so they must NOT be given one form between them -- a ray in one cone's shortcut zone would be culled by another's.
+    w = rt.World()
+    ow = orc.World()
+    w.light_source = rt.PointLight((-10, 10, -10), (1, 1, 1))
+    ow.set_light((-10, 10, -10), (1, 1, 1))
+    g = rt.Object.group()
+    og = ow.add(orc.GROUP, orc.identity())
+    s = 0.03
+    for k in range(24):
+        tilt = 4e-10 * k
+        if k % 3:
+            t = rt.Matrix4.translate(0.5 * k, 0, 0) * rt.Matrix4.rotate_z(tilt) * rt.Matrix4.scale(s, s, s)
+            ot = orc.mul(orc.mul(orc.translate(0.5 * k, 0, 0), orc.rotate_z(tilt)), orc.scale(s, s, s))
+            g.add_child(rt.Object(rt.CONE, transformation=t, minimum=-1.0, maximum=1.0))
+            ow.add(orc.CONE, ot, None, og, -1.0, 1.0, False)
+        else:
+            t = rt.Matrix4.translate(0.5 * k, 0, 0) * rt.Matrix4.scale(s, s, s)
+            g.add_child(rt.Object(rt.CUBE, transformation=t))
+            ow.add(orc.CUBE, orc.mul(orc.translate(0.5 * k, 0, 0), orc.scale(s, s, s)), None, og, 0.0, 0.0, False)
+    w.objects = [g]
+    ow.finalize()
+    rays = []
+    for k in range(24):
+        if k % 3 == 0:
+            continue
+        tilt = 4e-10 * k
+        for off in (-30.0, -4.0, 1.5, 12.0):
+            for eps in (0.0, 2e-7, -3e-7):  # a = dx^2 - dy^2 + dz^2 in the cone's space: 0 and a little either side of it
+                sx = 1.0 if off < 0 else -1.0
+                dx, dy = sx * math.cos(math.pi / 4 + eps + sx * tilt), -math.sin(math.pi / 4 + eps + sx * tilt)
+                # aimed at a point 0.25 cone units above the apex
+                rays.append([0.5 * k - dx * abs(off), 0.25 * s - dy * abs(off), 0.003, dx, dy, 0.0])
+    rays = np.array(rays)
+    assert sum(ow.hit(orc.ray(r[:3], r[3:])) is not None for r in rays) >= 20
+    _lone_rays_agree(orc, w.scene(), ow, rays)
 
 
 def test_ties_between_objects_in_reordered_lists(gpu, rt, orc):

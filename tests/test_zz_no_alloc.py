@@ -95,3 +95,67 @@ def test_noalloc_entry_point_refuses_what_it_cannot_do(gpu, rt, orc):
     assert L.lib().rt_render_device_noalloc(scene._h, ctypes.byref(cd), ctypes.byref(opts), ctypes.c_void_p(4096)) == -1
     opts.collect_stats, opts.flags = 0, L.RENDER_TIMED
     assert L.lib().rt_render_device_noalloc(scene._h, ctypes.byref(cd), ctypes.byref(opts), ctypes.c_void_p(4096)) == -1
+
+
+def test_noalloc_entry_point_allocates_nothing(gpu, rt, orc):
+    """The property the entry point exists for.  (1) hipMemGetInfo reports the same free memory before and after a run
+    of calls on frames of growing size (rt_render_device would have grown its scratch).  (2) The call can be captured
+    into a HIP graph in GLOBAL capture mode -- where an allocation, a synchronisation or an event creation by this
+    thread invalidates the capture -- and the replayed graph renders the frame rt_render_device renders."""
+    hip = Hip()
+    lib = hip.lib
+    lib.hipMemGetInfo.argtypes = [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    lib.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    lib.hipStreamBeginCapture.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.hipStreamEndCapture.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    lib.hipGraphInstantiate.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.hipGraphLaunch.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    lib.hipGraphExecDestroy.argtypes = [ctypes.c_void_p]
+    lib.hipGraphDestroy.argtypes = [ctypes.c_void_p]
+    lib.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    w, h = 640, 360
+    a, b = hip.alloc(w * h * 24), hip.alloc(w * h * 24)
+    stream = ctypes.c_void_p()
+    assert lib.hipStreamCreate(ctypes.byref(stream)) == 0
+    try:
+        for name in ("chapter_11", "chapter_14"):
+            cam, world, _, _ = load_both(rt, orc, name, w, h)
+            scene = world.scene()
+            scene.render_device(cam, a.value)
+            want = hip.fetch(a, (h, w, 3), np.float64)
+            # first use on this stream done: code objects loaded, the array's address resolved, and the runtime has
+            # given the stream's hardware queue its scratch memory for kernels with a per-lane stack (its doing, on a
+            # queue's first such launch, not the entry point's)
+            scene.render_device_noalloc(cam, b.value, stream=stream.value)
+            assert lib.hipDeviceSynchronize() == 0
+            free0, total = ctypes.c_size_t(), ctypes.c_size_t()
+            assert lib.hipMemGetInfo(ctypes.byref(free0), ctypes.byref(total)) == 0
+            for rows in ((0, 16), (0, 120), (0, h)):
+                scene.render_device_noalloc(cam, b.value, rows=rows, stream=stream.value)
+            assert lib.hipStreamSynchronize(stream) == 0
+            free1 = ctypes.c_size_t()
+            assert lib.hipMemGetInfo(ctypes.byref(free1), ctypes.byref(total)) == 0
+            assert free1.value == free0.value, "device memory was allocated during rt_render_device_noalloc"
+            assert np.array_equal(hip.fetch(b, (h, w, 3), np.float64), want)
+            # the same call under stream capture, replayed twice
+            assert lib.hipMemset(b, 0, w * h * 24) == 0 and lib.hipDeviceSynchronize() == 0
+            graph, graph_exec = ctypes.c_void_p(), ctypes.c_void_p()
+            assert lib.hipStreamBeginCapture(stream, 0) == 0  # hipStreamCaptureModeGlobal
+            try:
+                scene.render_device_noalloc(cam, b.value, stream=stream.value)
+            finally:
+                rc = lib.hipStreamEndCapture(stream, ctypes.byref(graph))
+            assert rc == 0 and graph.value, f"the capture was invalidated (hipStreamEndCapture: {rc})"
+            assert lib.hipGraphInstantiate(ctypes.byref(graph_exec), graph, None, None, 0) == 0
+            for _ in range(2):
+                assert lib.hipMemset(b, 0, w * h * 24) == 0 and lib.hipDeviceSynchronize() == 0
+                assert lib.hipGraphLaunch(graph_exec, stream) == 0
+                assert lib.hipStreamSynchronize(stream) == 0
+                assert np.array_equal(hip.fetch(b, (h, w, 3), np.float64), want)
+            lib.hipGraphExecDestroy(graph_exec)
+            lib.hipGraphDestroy(graph)
+    finally:
+        lib.hipStreamDestroy(stream)
+        lib.hipFree(a)
+        lib.hipFree(b)
