@@ -35,7 +35,8 @@ struct RtNode {
     int32_t leaf;     // index into RtSurface[], -1 for groups
     int32_t skip;     // index of the first node after this node's subtree
     double a[6];      // group: bounds min.xyz, max.xyz (in the group's own space); leaf: a[0]=minimum, a[1]=maximum;
-                      // range-skip node: box min.xyz, max.xyz
+                      // range-skip node: a[0..2] hold its box as SIX FLOATS, (min, max) per axis x, y, z, each rounded
+                      // away from the box's inside (the device tests it in f32); a[3..5] unused
 };
 #define RT_NODE_CLOSED 0x100
 #define RT_NODE_LEVEL_SHIFT 9
@@ -54,7 +55,7 @@ enum { RT_SKIP_PLAIN = 1, RT_SKIP_CONES = 3 };
 // A range-skip node X whose `skip` record R is a range-skip node of the same sibling list may carry R's test as well
 // (tag bit RT_NODE_LOOKAHEAD): when X rejects the wave, R is what the traversal would fetch and test next, so it is
 // tested at once and the traversal continues at R + 1 or at R's own `skip` without ever fetching R.  Then
-//   inv[7..9]  R's box as six floats (min.xyz, max.xyz), each rounded away from the box's inside
+//   inv[7..9]  R's box as R itself holds it: six floats, (min, max) per axis
 //   inv[10]    R's bound on |d^T q d| (0 when no cones lie below R); R shares X's q
 //   leaf       R's `skip`
 

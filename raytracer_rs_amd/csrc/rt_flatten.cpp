@@ -99,7 +99,7 @@ static size_t env_size(const char *name, size_t fallback) {
 static const size_t SKIP_MIN_LIST = env_size("RT_SKIP_MIN_LIST", 12);  // (developer override for tuning runs)
 // What a wave spends on one record, in vector instructions, the traversal loop's own share included: the figures
 // the choice of range-skip nodes is made with.  (Developer override: RT_COST_BOX.)
-static const double COST_BOX = (double)env_size("RT_COST_BOX", 60);  // a range-skip node: slab test, reach guard, its record
+static const double COST_BOX = (double)env_size("RT_COST_BOX", 40);  // a range-skip node: slab test, reach guard, its record
 static const double COST_RECORD = 20.0;                              // the loop's own work per record
 static const double COST_RAY_GENERAL = 33.0, COST_RAY_DIAGONAL = 9.0;  // the ray into a node's space
 static const double COST_BOUNDS = 75.0;                              // a group's bounds test with its six divisions
@@ -288,7 +288,17 @@ struct Builder {
             head.inv[6] = 2.0 * 1e-5 / dirs.lambda_min;  // twice EPSILON (core/floats.rs:2) / lambda
         }
         head.leaf = -1;
-        for (int i = 0; i < 6; ++i) head.a[i] = box[i];
+        // The device tests the box in f32: six floats, (min, max) per axis, each rounded away from the box's inside.
+        float f[6];
+        for (int axis = 0; axis < 3; ++axis) {
+            float lo = (float)box[axis], hi = (float)box[3 + axis];
+            if ((double)lo > box[axis]) lo = std::nextafterf(lo, -INFINITY);
+            if ((double)hi < box[3 + axis]) hi = std::nextafterf(hi, INFINITY);
+            f[2 * axis] = lo;
+            f[2 * axis + 1] = hi;
+        }
+        static_assert(sizeof f == 3 * sizeof(double), "six floats fill a[0..2]");
+        std::memcpy(&head.a[0], f, sizeof f);
         nodes->push_back(head);
         if (counting) out.n_skip_nodes++;
     }
@@ -588,15 +598,10 @@ static void add_lookahead(std::vector<RtNode> &table) {
             if (!same) continue;
             bound = r.inv[6];
         }
-        float box[6];
+        float box[6];  // R's own box, as R holds it
+        std::memcpy(box, &r.a[0], sizeof box);
         bool finite = true;
-        for (int k = 0; k < 6; ++k) {
-            float f = (float)r.a[k];
-            if (k < 3 && (double)f > r.a[k]) f = std::nextafterf(f, -INFINITY);
-            if (k >= 3 && (double)f < r.a[k]) f = std::nextafterf(f, INFINITY);
-            finite = finite && std::isfinite(f);
-            box[k] = f;
-        }
+        for (int k = 0; k < 6; ++k) finite = finite && std::isfinite(box[k]);
         if (!finite) continue;
         static_assert(sizeof(box) == 3 * sizeof(double), "six floats fill inv[7..9]");
         std::memcpy(&x.inv[7], box, sizeof box);

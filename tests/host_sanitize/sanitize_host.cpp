@@ -105,8 +105,10 @@ void feed(const std::string &text, Tally &tally) {
                 groups++;
                 open.emplace_back((size_t)n.skip, level + 1);
             } else if (kind == RT_SKIPBOX) {
+                float own[6];  // (min, max) per axis
+                std::memcpy(own, &n.a[0], sizeof own);
                 for (int a = 0; a < 3; ++a)
-                    if (!std::isfinite(n.a[a]) || !std::isfinite(n.a[3 + a]) || n.a[a] > n.a[3 + a]) fail("range-skip box is not a box", t * per_table + i);
+                    if (!std::isfinite(own[2 * a]) || !std::isfinite(own[2 * a + 1]) || own[2 * a] > own[2 * a + 1]) fail("range-skip box is not a box", t * per_table + i);
                 if ((size_t)n.skip == i + 1) fail("range-skip node in front of nothing", t * per_table + i);
                 if (n.tag & RT_NODE_LOOKAHEAD) {  // carries the test of the range-skip node at `skip`
                     const RtNode &r = tab[(size_t)n.skip];
@@ -115,8 +117,7 @@ void feed(const std::string &text, Tally &tally) {
                     bool holds = (size_t)n.skip + 1 < per_table && (r.tag & 0xff) == RT_SKIPBOX &&
                                  ((r.tag >> RT_NODE_LEVEL_SHIFT) & RT_NODE_LEVEL_MASK) == level && n.leaf == r.skip &&
                                  n.inv[10] == (r.xform == RT_SKIP_CONES ? r.inv[6] : 0.0) && (r.xform != RT_SKIP_CONES || n.xform == RT_SKIP_CONES);
-                    for (int a = 0; a < 3 && holds; ++a)
-                        holds = std::isfinite(box[a]) && std::isfinite(box[3 + a]) && (double)box[a] <= r.a[a] && (double)box[3 + a] >= r.a[3 + a];
+                    holds = holds && std::memcmp(box, &r.a[0], sizeof box) == 0;
                     if (!holds) fail("range-skip node carries a test that is not its successor's", t * per_table + i);
                 }
                 open.emplace_back((size_t)n.skip, level);
