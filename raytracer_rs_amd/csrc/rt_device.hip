@@ -563,6 +563,42 @@ __device__ __forceinline__ bool box_may_hit32(f32x2 bx, f32x2 by, f32x2 bz, cons
     return !((miss | behind | beyond) & near);
 }
 
+// Bounds::intersects (geometry/bounds.rs:94-128) decided in f32 whenever f32 can be SURE of the reference's answer.
+// The reference's test is six f64 divisions (some 130 instructions as the compiler expands them); the same slab
+// arithmetic in f32 -- packed, reciprocals instead of divisions -- is a third of that, and its result is the
+// reference's whenever the two interval ends it compares are further apart than everything f32 may have lost:
+//   * origin and box rounded to f32 (2^-24 of their magnitudes each), differences, reciprocal directions (2^-22
+//     relative) and products: |t_f32 - t_reference| <= 2^-22 pmax imax + 2^-21 |t| with pmax the largest |coordinate|
+//     of origin and box and imax the largest |1/d|; the room demanded is 2^-19 pmax imax + 8e-6 max(|tmin|, |tmax|),
+//     eight and more times that;
+//   * every |d| must exceed 1e-6: the reference then divides (its threshold for the `* INFINITY` branch is 1e-10) and
+//     nothing here is near a special case; infinite bounds, overflow and NaN make a comparison false, and a false
+//     comparison means "not sure".
+// Returns true when sure, with the reference's answer in `hit`.  When some ray of a wave is not sure, the caller
+// runs the reference's arithmetic (aabb_hit) for the wave.
+__device__ __forceinline__ bool aabb_sure(const double (&bb)[6], V3 o, V3 d, bool &hit) {
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    const bool regular = __builtin_fminf(__builtin_fminf(fabsf(dx), fabsf(dy)), fabsf(dz)) > 1e-6f;
+    const float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
+    f32x2 bx, by, bz;
+    bx.x = (float)bb[0], bx.y = (float)bb[3];
+    by.x = (float)bb[1], by.y = (float)bb[4];
+    bz.x = (float)bb[2], bz.y = (float)bb[5];
+    const f32x2 tx = (bx - ox) * ix, ty = (by - oy) * iy, tz = (bz - oz) * iz;
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)), __builtin_fminf(tz.x, tz.y));
+    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)), __builtin_fmaxf(tz.x, tz.y));
+    const float imax = __builtin_fmaxf(__builtin_fmaxf(fabsf(ix), fabsf(iy)), fabsf(iz));
+    const float bmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(fabsf(bx.x), fabsf(bx.y)), __builtin_fmaxf(fabsf(by.x), fabsf(by.y))),
+                                       __builtin_fmaxf(fabsf(bz.x), fabsf(bz.y)));
+    const float pmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)), bmax);
+    const float room = __builtin_fmaf(__builtin_fmaxf(fabsf(tmin), fabsf(tmax)), 8e-6f, 0x1p-19f * pmax * imax);
+    const float gap = tmax - tmin;
+    hit = gap > room;            // tmin <= tmax beyond doubt
+    const bool miss = -gap > room;  // tmin > tmax beyond doubt
+    return regular & (hit | miss);
+}
+
 // The control words of a node record, moved to registers of their own: nothing of the record is needed once the ray
 // has been transformed, so the next record can be loaded where this one lies.
 // (readfirstlane on the operands: the asm wants scalar registers whatever the optimiser has come to believe about the
@@ -831,10 +867,13 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
             // Group: bounds in the group's own space against the ray in that space (world.rs:44-63)
             bool inside = false;
             if (active) {
-                inside = aabb_hit(bb, lo, ld);
                 ctr.add(C_XFORM);
                 ctr.add(C_AABB);
             }
+            // in f32 when every ray's answer is beyond doubt (all but rays that graze the bounds), else as the reference does
+            bool sure = true;
+            if (active) sure = aabb_sure(bb, lo, ld, inside);
+            if (__ballot(!sure) != 0ull) inside = active && aabb_hit(bb, lo, ld);
             if constexpr (!STATS) ctr.visits += inside ? 4u : 0u;
             ni = w.skip;
             if (__ballot(inside) != 0ull && w.skip != i + 1) {  // (a group without children has nothing to walk)
