@@ -1642,15 +1642,19 @@ __global__ __launch_bounds__(ORDER_BLOCK) void order_scatter_kernel(RowMap rows,
 
 // Camera::render (rendering/camera.rs:56-67) for the rows of `rows`: one wave per 8x8 pixel tile.
 // Launched with one wave per workgroup (RENDER_BLOCK).  Flat scenes: four waves per SIMD, a budget of 128 VGPRs per
-// lane, which that kernel fits without spilling.  Scenes with groups: five waves per SIMD (96 VGPRs, some fifty of the
-// traversal's values spilled): their node tables do not fit the scalar cache, the record fetches miss, and a fifth
-// wave to switch to is worth more than the spills cost (chapter_14 at 4K -3 %, the generated scene at 8K -6 %; six
-// and eight waves gain nothing more).
+// lane, which that kernel fits without spilling.  The general build for scenes with groups (NEST 1): five waves per
+// SIMD (96 VGPRs, over a hundred of the traversal's values spilled): its node tables run to megabytes, the record
+// fetches miss the scalar cache, and a fifth wave to switch to is worth more than the spills cost (the generated scene
+// at 8K: 70.4 ms against 74.3 at four waves; six waves 72.1).  The build without cone directions (NEST 2: chapter_14,
+// whose table is 0.1 MB): four waves, no spilled vector registers -- 4.50 ms against 4.60 at five.
 template <bool STATS, int NEST, bool TIES>
 #ifndef RT_NEST_WAVES
 #define RT_NEST_WAVES 5
 #endif
-__global__ __launch_bounds__(RENDER_BLOCK, NEST > 0 ? RT_NEST_WAVES : 4) void render_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth,
+#ifndef RT_NEST2_WAVES
+#define RT_NEST2_WAVES 4
+#endif
+__global__ __launch_bounds__(RENDER_BLOCK, NEST == 2 ? RT_NEST2_WAVES : NEST > 0 ? RT_NEST_WAVES : 4) void render_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth,
                                                      double *__restrict__ rgb, unsigned long long *counters) {
     const unsigned lane = threadIdx.x & 63;
     unsigned tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
