@@ -30,6 +30,7 @@ def main() -> None:
     ap.add_argument("--flops", type=float, default=0.0, help="default: the figure perf.py printed in the kernel-trace run")
     ap.add_argument("--resource-usage", default=None)
     ap.add_argument("--note", default="")
+    ap.add_argument("--config", default=None, help="also record HBM bytes and executed flops under this name in profiles/pmc_traffic.json")
     a = ap.parse_args()
     src = os.path.join(ROOT, "gpurun_out", f"prof_{a.tag}")
     dst = os.path.join(ROOT, "profiles")
@@ -126,6 +127,18 @@ def main() -> None:
         derived.append(f"HBM traffic per launch ~ {(2 * fetch_b + write_b) / 1e6:.1f} MB: fetch {2 * fetch_b / 1e6:.1f} MB (FETCH_SIZE KB x 1024 x 2, "
                        f"the gfx950 correction for wide reads), write {write_b / 1e6:.1f} MB (WRITE_SIZE KB x 1024)")
     lines += ["## Derived", ""] + [f"* {d}" for d in derived] + [""]
+    if a.config and ("FETCH_SIZE" in mean or "WRITE_SIZE" in mean):
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from summarize_profile import merge_pmc_entry
+
+        entry = {"fetch_kb_reported": g("FETCH_SIZE"), "write_kb_reported": g("WRITE_SIZE"),
+                 "hbm_bytes_per_launch": 2.0 * g("FETCH_SIZE", 0.0) * 1024.0 + g("WRITE_SIZE", 0.0) * 1024.0, "profile": f"{a.tag}_summary.md"}
+        f64 = [g(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")]
+        if sum(f64):
+            entry["executed_f64_flops_per_launch"] = (f64[0] + f64[1] + 2 * f64[2] + f64[3]) * 64
+        merge_pmc_entry(dst, a.config, entry)
 
     if a.resource_usage and kernel_full:
         import subprocess
