@@ -159,7 +159,9 @@ typedef struct rt_scene_info {
     uint64_t device_bytes;
     int32_t device;
     int32_t kernel_build; /* which build of the render kernel serves this world: 0 = a table of leaves only (no groups, at
-                             most 12 objects), 1 = any table, 2 = a table in which no range of nodes holds a cone */
+                             most 12 objects), 1 = any table, 2 = a table in which no range of nodes holds a cone,
+                             3 = a large hierarchy, rendered level by level of its ray trees through queues in device
+                             memory (rt_render_device_noalloc refuses such a world) */
 } rt_scene_info;
 
 /* struct Computations (rendering/intersections.rs:12-24); `object` is an index into rt_world_desc.objects. */

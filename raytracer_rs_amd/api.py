@@ -609,6 +609,12 @@ class World:
             self._scene = Scene(wd, device, keepalive=keep)
         return self._scene
 
+    def release_scene(self) -> None:
+        """Destroys the GPU copy of the world; the next scene() makes a new one (and reads the environment again)."""
+        if self._scene is not None:
+            self._scene.close()
+            self._scene = None
+
     # rendering/world.rs:27-36 + intersections.rs:37-39: the hit of one ray, or None
     def hit(self, ray: Ray) -> Optional[Tuple[float, int]]:
         t, obj = self.scene().intersect(np.array([list(ray.origin) + list(ray.direction)]))

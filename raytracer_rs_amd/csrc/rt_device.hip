@@ -20,6 +20,7 @@
 //   * no MFMA: nothing on this path is a dense contraction.  The node table is read through the scalar cache, the
 //     per-hit surface records through the vector L1; LDS holds only the ray stacks.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>  // launch_render_levels scans its per-wave ray counts
 
 #include <cstddef>
 #include <cstdlib>
@@ -1640,6 +1641,63 @@ __global__ __launch_bounds__(ORDER_BLOCK) void order_scatter_kernel(RowMap rows,
     if (valid) scratch[TILE_HEADER + before[cls] + slot] = tile;
 }
 
+// Canvas::write_pixel (rendering/canvas.rs:26-32) for one 8x8 tile held by one wave: lane (lane & 7, lane >> 3) has
+// the colour of pixel x of packed row r (frame row y).  `staging` is LDS of the wave's own, 1 536 bytes at least.
+__device__ __forceinline__ void store_tile(const RtCameraDev &cam, const RowMap &rows, unsigned tile, unsigned lane, bool valid, unsigned x,
+                                           unsigned r, unsigned y, V3 acc, double *staging, double *__restrict__ rgb) {
+    const unsigned tiles_x = (cam.hsize + 7) >> 3;
+    // Canvas::write_pixel (rendering/canvas.rs:26-32) for the tile.  A lane's pixel is 3 values in the middle of a
+    // row, so lanes storing their own pixels write 24-byte (or 3-byte) pieces 24 (3) bytes apart.  A whole tile is
+    // instead laid out in LDS as its 8 rows of 24 values (the pending-ray stack is empty by now and lends the space)
+    // and stored row by row with consecutive lanes on consecutive words: 8-byte stores covering 192 contiguous bytes
+    // per tile row for the f64 canvas, one dword per lane for the 8-bit frame.
+    // Where the rows land: packed one after the other from the start of the buffer, or (rows.in_place) at their own
+    // place in a whole frame.  A tile's eight rows are consecutive frame rows when bands are whole tiles high.
+    const unsigned r_out = rows.in_place ? y : r;
+    const unsigned tile_row_out = rows.in_place ? image_row(rows, (tile / tiles_x) * 8) : (tile / tiles_x) * 8;
+    const size_t idx = ((size_t)r_out * cam.hsize + x) * 3;  // Canvas index (canvas.rs:40-42)
+    const bool whole_tile = __ballot(valid) == ~0ull && (!rows.in_place || (rows.band_rows & 7u) == 0u);
+    if (rows.quantized) {
+        const unsigned q0 = quantize_value(acc.x), q1 = quantize_value(acc.y), q2 = quantize_value(acc.z);
+        const size_t row_bytes = (size_t)cam.hsize * 3;
+        uint8_t *tile0 = rows.quantized + (size_t)tile_row_out * row_bytes + (size_t)((tile % tiles_x) * 8) * 3;
+        if (whole_tile && ((row_bytes | reinterpret_cast<size_t>(rows.quantized)) & 3) == 0) {
+            uint8_t *bytes = reinterpret_cast<uint8_t *>(staging);  // 8 rows x 24 bytes
+            const unsigned at = (lane >> 3) * 24 + (lane & 7) * 3;
+            bytes[at] = (uint8_t)q0;
+            bytes[at + 1] = (uint8_t)q1;
+            bytes[at + 2] = (uint8_t)q2;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 48) {  // 6 dwords per tile row
+                const unsigned row = lane / 6, word = lane % 6;
+                const unsigned v = reinterpret_cast<const unsigned *>(bytes)[row * 6 + word];
+                *reinterpret_cast<unsigned *>(tile0 + row * row_bytes + word * 4) = v;
+            }
+        } else if (valid) {
+            rows.quantized[idx] = (uint8_t)q0;
+            rows.quantized[idx + 1] = (uint8_t)q1;
+            rows.quantized[idx + 2] = (uint8_t)q2;
+        }
+    } else if (whole_tile) {
+        double *vals = staging;  // 8 rows x 24 doubles
+        const unsigned at = (lane >> 3) * 24 + (lane & 7) * 3;
+        vals[at] = acc.x;
+        vals[at + 1] = acc.y;
+        vals[at + 2] = acc.z;
+        __builtin_amdgcn_wave_barrier();
+        double *tile0 = rgb + ((size_t)tile_row_out * cam.hsize + (size_t)((tile % tiles_x) * 8)) * 3;
+#pragma unroll
+        for (unsigned k = 0; k < 3; ++k) {
+            const unsigned j = lane + 64 * k;  // 192 values
+            tile0[(size_t)(j / 24) * cam.hsize * 3 + j % 24] = vals[j];
+        }
+    } else if (valid) {
+        rgb[idx] = acc.x;
+        rgb[idx + 1] = acc.y;
+        rgb[idx + 2] = acc.z;
+    }
+}
+
 // Camera::render (rendering/camera.rs:56-67) for the rows of `rows`: one wave per 8x8 pixel tile.
 // Launched with one wave per workgroup (RENDER_BLOCK).  Flat scenes: four waves per SIMD, a budget of 128 VGPRs per
 // lane, which that kernel fits without spilling.  The general build for scenes with groups (NEST 1): five waves per
@@ -1680,56 +1738,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, NEST == 2 ? RT_NEST2_WAVES : NEST > 0
 #ifdef RT_TIMING
     if (lane == 0 && blockIdx.x < RT_TIMING_WAVES) g_rt_timing[blockIdx.x][6] = tile;
 #endif
-    // Canvas::write_pixel (rendering/canvas.rs:26-32) for the tile.  A lane's pixel is 3 values in the middle of a
-    // row, so lanes storing their own pixels write 24-byte (or 3-byte) pieces 24 (3) bytes apart.  A whole tile is
-    // instead laid out in LDS as its 8 rows of 24 values (the pending-ray stack is empty by now and lends the space)
-    // and stored row by row with consecutive lanes on consecutive words: 8-byte stores covering 192 contiguous bytes
-    // per tile row for the f64 canvas, one dword per lane for the 8-bit frame.
-    // Where the rows land: packed one after the other from the start of the buffer, or (rows.in_place) at their own
-    // place in a whole frame.  A tile's eight rows are consecutive frame rows when bands are whole tiles high.
-    const unsigned r_out = rows.in_place ? y : r;
-    const unsigned tile_row_out = rows.in_place ? image_row(rows, (tile / tiles_x) * 8) : (tile / tiles_x) * 8;
-    const size_t idx = ((size_t)r_out * cam.hsize + x) * 3;  // Canvas index (canvas.rs:40-42)
-    const bool whole_tile = __ballot(valid) == ~0ull && (!rows.in_place || (rows.band_rows & 7u) == 0u);
-    if (rows.quantized) {
-        const unsigned q0 = quantize_value(acc.x), q1 = quantize_value(acc.y), q2 = quantize_value(acc.z);
-        const size_t row_bytes = (size_t)cam.hsize * 3;
-        uint8_t *tile0 = rows.quantized + (size_t)tile_row_out * row_bytes + (size_t)((tile % tiles_x) * 8) * 3;
-        if (whole_tile && ((row_bytes | reinterpret_cast<size_t>(rows.quantized)) & 3) == 0) {
-            uint8_t *bytes = reinterpret_cast<uint8_t *>(ray_stack_lds + S.stack_base);  // 8 rows x 24 bytes
-            const unsigned at = (lane >> 3) * 24 + (lane & 7) * 3;
-            bytes[at] = (uint8_t)q0;
-            bytes[at + 1] = (uint8_t)q1;
-            bytes[at + 2] = (uint8_t)q2;
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 48) {  // 6 dwords per tile row
-                const unsigned row = lane / 6, word = lane % 6;
-                const unsigned v = reinterpret_cast<const unsigned *>(bytes)[row * 6 + word];
-                *reinterpret_cast<unsigned *>(tile0 + row * row_bytes + word * 4) = v;
-            }
-        } else if (valid) {
-            rows.quantized[idx] = (uint8_t)q0;
-            rows.quantized[idx + 1] = (uint8_t)q1;
-            rows.quantized[idx + 2] = (uint8_t)q2;
-        }
-    } else if (whole_tile) {
-        double *vals = ray_stack_lds + S.stack_base;  // 8 rows x 24 doubles
-        const unsigned at = (lane >> 3) * 24 + (lane & 7) * 3;
-        vals[at] = acc.x;
-        vals[at + 1] = acc.y;
-        vals[at + 2] = acc.z;
-        __builtin_amdgcn_wave_barrier();
-        double *tile0 = rgb + ((size_t)tile_row_out * cam.hsize + (size_t)((tile % tiles_x) * 8)) * 3;
-#pragma unroll
-        for (unsigned k = 0; k < 3; ++k) {
-            const unsigned j = lane + 64 * k;  // 192 values
-            tile0[(size_t)(j / 24) * cam.hsize * 3 + j % 24] = vals[j];
-        }
-    } else if (valid) {
-        rgb[idx] = acc.x;
-        rgb[idx + 1] = acc.y;
-        rgb[idx + 2] = acc.z;
-    }
+    store_tile(cam, rows, tile, lane, valid, x, r, y, acc, ray_stack_lds + S.stack_base, rgb);
     flush_counters<STATS>(ctr, counters);
 }
 
@@ -2030,6 +2039,8 @@ static void launch_render_nest(int nest, dim3 grid, unsigned block, hipStream_t 
     else RT_LAUNCH(1, false);
 #undef RT_LAUNCH
 }
+
+#include "rt_levels.inl"
 
 size_t render_scratch_words(uint32_t hsize, uint32_t n_rows) {
     return TILE_HEADER + 3 * (size_t)((hsize + 7) / 8) * ((n_rows + 7) / 8);

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include "../../include/raytracer_rs_amd.h"
 #include "rt_device_types.h"
 
 namespace rt {
@@ -38,6 +39,28 @@ struct RowMap {
                                           // in it (index = frame row), not packed after the rows rendered before it
 };
 
+// Device memory of the level-by-level renderer (launch_render_levels), owned by whoever owns the scene (one arena per
+// scene handle; one frame at a time).  Buffers grow on demand and are kept between frames.
+struct ArenaBuffer {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+constexpr int LEVELS_MAX = RT_MAX_DEPTH + 1;  // level 0 = the rays through the pixels, level k = their k-th generation of children
+struct LevelArena {
+    ArenaBuffer queue_f[2], queue_rem[2];  // the rays a level reads and the rays it writes (origin, direction, weight; remaining budget)
+    ArenaBuffer counts;                    // children per wave and kind of the level being rendered
+    ArenaBuffer offsets[LEVELS_MAX];       // the same, scanned: where a wave's children stand in the next level (kept for the sums)
+    ArenaBuffer index;                     // ray number in the next level -> its slot in the queue
+    ArenaBuffer terms[LEVELS_MAX];         // per ray of a level: its term of its pixel's sum, then the sum over its subtree
+    ArenaBuffer links[LEVELS_MAX];         // per ray of a level: which of its wave's children are its own
+    ArenaBuffer scan_temp;
+    uint32_t *host_totals = nullptr;        // pinned: the level's child totals as the host reads them
+    uint32_t levels = 0;                    // of the last frame: levels rendered, rays per level
+    uint32_t level_rays[LEVELS_MAX] = {};
+    size_t device_bytes() const;
+};
+void level_arena_release(LevelArena &arena);
+
 // Number of 32-bit words of device scratch launch_render needs for a frame of hsize x n_rows pixels.
 size_t render_scratch_words(uint32_t hsize, uint32_t n_rows);
 // Camera::render over the rows of `rows`: rgb receives n_rows*hsize*3 doubles.
@@ -51,6 +74,14 @@ size_t render_scratch_words(uint32_t hsize, uint32_t n_rows);
 hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows, int max_depth,
                          double *rgb, unsigned long long *counters, uint32_t *tile_scratch, hipStream_t stream,
                          hipEvent_t *marks = nullptr, bool order_cached = false);
+// The same frame rendered level by level: one launch for the rays through the pixels, then one per generation of
+// reflection and refraction rays, each wave taking 64 rays of one kind from neighbouring pixels off a queue in device
+// memory, and a pass that adds every ray's term to its parent's, children before parents.  For scenes with groups
+// only (the kernels walk node tables with groups).  Blocks the calling thread between levels (it reads how many rays
+// the next level has) and may allocate device memory (the arena grows to the frame's needs).  marks as above; the
+// tile-ordering pass does not exist here, so marks[0] and marks[1] are recorded together.
+hipError_t launch_render_levels(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows, int max_depth,
+                                double *rgb, LevelArena &arena, hipStream_t stream, hipEvent_t *marks = nullptr);
 // The tile-ordering scratch that lives in a static device array (one copy per GPU) instead of allocated memory:
 // static_render_scratch_resolve(device) looks its address up once per device -- call it with `device` current, at
 // set-up; static_render_scratch(device) returns that address afterwards (nullptr when it was never resolved).  The

@@ -1,0 +1,397 @@
+// Camera::render (rendering/camera.rs:56-67) level by level, for scenes with groups.  Included by rt_device.hip inside
+// namespace rt, after the traversal, shading and tile-store code it shares with render_kernel.
+//
+// render_kernel keeps a pixel's pending reflection and refraction rays on a per-lane stack and walks them in the
+// pixel's own wave, round after round; deep in the ray trees the 64 lanes of a wave hold rays of different
+// generations and kinds, the wave walks the union of their paths through the node tables, and the state it carries
+// across a traversal no longer fits the registers of five waves per SIMD.  Here a launch renders ONE level of every
+// ray tree:
+//
+//   level 0      one wave per 8x8 pixel tile (tiles taken in 8x8 blocks, so that consecutive waves are neighbours in
+//                both directions): ray through the pixel, closest hit, shading, shadow ray;
+//   level k > 0  one wave per 64 consecutive rays of the queue the level before wrote.
+//
+// A wave writes the reflection and refraction rays it spawns into slots of its own (64 per kind), counts them, and an
+// exclusive scan of the counts numbers the next level's rays: all reflections first, then all refractions, each in the
+// order of their parent waves -- screen order, roughly, at every level, so a wave's 64 rays are of one kind and from
+// neighbouring pixels.  (Appending in the order in which waves happen to finish mixes rays from all over the frame:
+// measured, the deeper levels then take three to four times as long.)
+//
+// Sums.  Each ray stores its term of its pixel's colour (path weight x surface colour, as in radiance()) under its own
+// number and remembers which of its wave's children are its own; when the last level is done, one pass per level,
+// deepest first, adds to every ray the sums of its two children -- reflection, then refraction: the order of
+// world.rs:107-110.  A pixel's colour is therefore a function of its own ray tree alone: it does not depend on the
+// launch, the rows rendered with it, or the order in which waves run.
+// Waves per SIMD: six (80 VGPRs) for the general build, whose node tables are large and whose record fetches miss the
+// scalar cache -- the generated scene at 8K 62.7 ms against 63.8 at five and 68.9 at four; five for the build without
+// cone directions (chapter_14 with levels forced: 4.5 ms at five, 4.8 at four, 5.0 at six).
+#ifndef RT_LEVEL_WAVES
+#define RT_LEVEL_WAVES(NEST) ((NEST) == 2 ? 5 : 6)
+#endif
+
+namespace {
+
+constexpr unsigned NO_CHILD = 0xffu;
+
+struct LevelIO {
+    // the rays of this level (unused at level 0)
+    const double *in_f = nullptr;       // seven arrays of in_slots doubles: origin, direction, weight
+    const uint8_t *in_rem = nullptr;    // remaining recursion budget
+    size_t in_slots = 0;
+    const uint32_t *in_index = nullptr; // ray number -> slot
+    uint32_t n_rays = 0;
+    // what it writes
+    double *out_f = nullptr;            // 128 slots per wave: kind * 64 * waves + wave * 64 + k
+    uint8_t *out_rem = nullptr;
+    uint32_t *out_counts = nullptr;     // [2][waves + 1]
+    uint32_t waves = 0;
+    double *terms = nullptr;            // three arrays of 64 * waves doubles
+    uint8_t *links = nullptr;           // two arrays of 64 * waves bytes: k of the ray's reflection / refraction, or NO_CHILD
+    uint32_t blocks_x = 0;              // level 0: blocks of 8x8 tiles per row of blocks
+};
+
+// Level 0: which tile wave `wave` renders.  Tiles go in blocks of 8x8; a block on the right or lower edge may hold
+// tiles outside the frame.
+__device__ __forceinline__ bool level0_tile(unsigned wave, unsigned blocks_x, unsigned tiles_x, unsigned tiles_y, unsigned &tile) {
+    const unsigned block = wave >> 6, within = wave & 63u;
+    const unsigned tx = (block % blocks_x) * 8 + (within & 7u), ty = (block / blocks_x) * 8 + (within >> 3);
+    tile = ty * tiles_x + tx;
+    return tx < tiles_x && ty < tiles_y;
+}
+
+template <int NEST, bool TIES, bool FIRST>
+__global__ __launch_bounds__(64, RT_LEVEL_WAVES(NEST)) void level_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth, LevelIO io) {
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned wave = blockIdx.x;
+    SceneK S = scene_k<NEST, false>(scene, max_depth);
+    Ctr<false> ctr;
+    V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+    double w = 1.0;
+    int remaining = max_depth;
+    bool have;
+    if constexpr (FIRST) {
+        const unsigned tiles_x = (cam.hsize + 7) >> 3, tiles_y = (rows.n_rows + 7) >> 3;
+        unsigned tile;
+        const bool tile_ok = level0_tile(wave, io.blocks_x, tiles_x, tiles_y, tile);
+        const unsigned x = (tile % tiles_x) * 8 + (lane & 7);
+        const unsigned r = (tile / tiles_x) * 8 + (lane >> 3);
+        const unsigned y = image_row(rows, r);
+        have = tile_ok && x < cam.hsize && r < rows.n_rows && y < rows.row_end;
+        if (have) ray_for_pixel(cam, x, y, ro, rd);
+    } else {
+        const unsigned i = wave * 64 + lane;
+        have = i < io.n_rays;
+        if (have) {
+            const unsigned slot = io.in_index[i];
+            const double *f = io.in_f + slot;
+            const size_t c = io.in_slots;
+            ro = mk(f[0], f[c], f[2 * c]);
+            rd = mk(f[3 * c], f[4 * c], f[5 * c]);
+            w = f[6 * c];
+            remaining = io.in_rem[slot];
+        }
+    }
+    const size_t out_slots = (size_t)io.waves * 128;
+    if (FIRST && __ballot(have) == 0ull) {  // a tile outside the frame (the launch is padded to whole blocks of tiles)
+        const size_t n = (size_t)io.waves * 64, i = (size_t)wave * 64 + lane;
+        if (lane < 2) io.out_counts[lane * (io.waves + 1u) + wave] = 0u;
+        io.terms[i] = 0.0, io.terms[n + i] = 0.0, io.terms[2 * n + i] = 0.0;
+        io.links[i] = (uint8_t)NO_CHILD, io.links[n + i] = (uint8_t)NO_CHILD;
+        return;
+    }
+    // The wave's children of one kind, packed into its 64 slots for that kind; returns the lane's k (NO_CHILD if none).
+    auto append = [&](bool want, unsigned kind, V3 o, V3 d, double pw, int prem) -> unsigned {
+        const unsigned long long m = __ballot(want);
+        if (lane == 0) io.out_counts[kind * (io.waves + 1u) + wave] = (unsigned)__popcll(m);
+        if (!want) return NO_CHILD;
+        const unsigned k = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        const size_t slot = (size_t)kind * 64 * io.waves + (size_t)wave * 64 + k;
+        double *f = io.out_f + slot;
+        f[0] = o.x, f[out_slots] = o.y, f[2 * out_slots] = o.z;
+        f[3 * out_slots] = d.x, f[4 * out_slots] = d.y, f[5 * out_slots] = d.z;
+        f[6 * out_slots] = pw;
+        io.out_rem[slot] = (uint8_t)prem;
+        return k;
+    };
+
+    const V3 light_pos = mk(S.light.position[0], S.light.position[1], S.light.position[2]);
+    const Closest<TIES> best = trace<NEST, false, TIES>(S, ro, rd, have, (double)INFINITY, ctr);
+    const bool shade = have && best.leaf >= 0 && S.light.has_light;  // else black: world.rs:124, world.rs:86-89
+    V3 term_lit = mk(0.0, 0.0, 0.0), term = mk(0.0, 0.0, 0.0);
+    V3 sro = ro, srd = rd;
+    double h_dist = 0.0;
+    int h_flags = 0;
+    bool do_reflect = false, do_refract = false;
+    V3 refl_o = ro, refl_d = rd, refr_o = ro, refr_d = rd;
+    double w_reflect = 0.0, w_refract = 0.0;
+    if (shade) {
+        // Intersection::prepare_computations (rendering/intersections.rs:45-63), Material::lighting for both outcomes
+        // of the shadow test, the children's rays and weights: the arithmetic of radiance(), statement for statement.
+        const RtSurface *s = S.surfaces + best.leaf;
+        V3 point = ro + rd * best.t;
+        V3 object_point;
+        V3 normal = normal_at<false>(s, point, object_point);
+        V3 eye = -rd;
+        const bool from_inside = dot(normal, eye) < 0.0;
+        if (from_inside) normal = -normal;
+        V3 over = point + normal * EPS;
+        V3 shadowed, lit;
+        lighting<false>(s, S.light, point, object_point, eye, normal, shadowed, lit, h_flags, ctr);
+        term_lit = lit * w;
+        term = shadowed * w;
+        const double reflectivity = s->reflectivity;
+        const double transparency = s->transparency;
+        do_reflect = remaining != 0 && reflectivity != 0.0;   // world.rs:156-162
+        do_refract = remaining != 0 && transparency != 0.0;   // world.rs:175-181
+        double cos_i = dot(eye, normal);
+        const double n1 = 1.0;  // (intersections.rs:41-43,66-103 on the one-element list: see radiance())
+        const double n2 = (fabs(best.t - best.t) < EPS) ? s->refractive_index : 1.0;
+        if (do_refract) {  // world.rs:183-194
+            double n_ratio = n1 / n2;
+            double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+            if (sin2_t > 1.0) {
+                do_refract = false;
+            } else {
+                double cos_t = sqrt(1.0 - sin2_t);
+                refr_d = normal * (n_ratio * cos_i - cos_t) - eye * n_ratio;
+            }
+        }
+        w_reflect = w * reflectivity;
+        w_refract = w * transparency;
+        if (reflectivity > 0.0 && transparency > 0.0) {  // world.rs:105-108, intersections.rs:123-136
+            double c = cos_i;
+            double reflectance;
+            bool total = false;
+            if (n1 > n2) {
+                double n = n1 / n2;
+                double sin2_t = (n * n) * (1.0 - c * c);
+                if (sin2_t > 1.0) total = true;
+                c = sqrt(1.0 - sin2_t);
+            }
+            if (total) {
+                reflectance = 1.0;
+            } else {
+                double q = (n1 - n2) / (n1 + n2);
+                double r0 = q * q;
+                double m = 1.0 - c;
+                double m2 = m * m;
+                double m5 = m * (m2 * m2);  // powi(5)
+                reflectance = r0 + (1.0 - r0) * m5;
+            }
+            w_reflect = w_reflect * reflectance;
+            w_refract = w_refract * (1.0 - reflectance);
+        }
+        refl_o = over;  // over_point, reflect_vector (intersections.rs:60-62)
+        refl_d = reflect(rd, normal);
+        refr_o = point - normal * EPS;  // under_point (intersections.rs:63)
+        V3 v = light_pos - over;  // World::is_shadowed (rendering/world.rs:128-141)
+        h_dist = magnitude(v);
+        sro = over;
+        srd = div_by_magnitude(v, h_dist);
+    }
+    const unsigned k_reflect = append(shade && do_reflect, 0u, refl_o, refl_d, w_reflect, remaining - 1);
+    const unsigned k_refract = append(shade && do_refract, 1u, refr_o, refr_d, w_refract, remaining - 1);
+    if (__ballot(shade) != 0ull) {
+        const bool in_shadow = occluded<NEST, false>(S, sro, srd, shade, h_dist, ctr);  // world.rs:145-148
+        if (shade && !in_shadow) term = term_lit;
+    }
+    const size_t n = (size_t)io.waves * 64, i = (size_t)wave * 64 + lane;
+    io.terms[i] = term.x;
+    io.terms[n + i] = term.y;
+    io.terms[2 * n + i] = term.z;
+    io.links[i] = (uint8_t)k_reflect;
+    io.links[n + i] = (uint8_t)k_refract;
+}
+
+// Ray number in the next level -> queue slot: child k of kind `kind` of parent wave p is ray
+// (kind ? all reflections : 0) + offsets[kind][p] + k and lies in slot kind * 64 * waves + p * 64 + k.
+__global__ __launch_bounds__(256) void level_index_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets, uint32_t waves,
+                                                          uint32_t *__restrict__ index) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)waves * 128) return;
+    const unsigned kind = t >= (size_t)waves * 64 ? 1u : 0u;
+    const unsigned p = (unsigned)((t - (size_t)kind * 64 * waves) >> 6), k = (unsigned)(t & 63u);
+    if (k >= counts[kind * (waves + 1u) + p]) return;
+    const unsigned first = kind ? offsets[waves] : 0u;
+    index[first + offsets[kind * (waves + 1u) + p] + k] = (uint32_t)t;
+}
+
+// Children before parents: a ray's sum = its own term + the sum of its reflection + the sum of its refraction
+// (the order of world.rs:107-110).  `child` holds the finished sums of the next level.
+__global__ __launch_bounds__(256) void level_sum_kernel(double *__restrict__ terms, const uint8_t *__restrict__ links, const uint32_t *__restrict__ offsets,
+                                                        uint32_t waves, uint32_t n_rays, const double *__restrict__ child, size_t child_n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays) return;
+    const size_t n = (size_t)waves * 64;
+    const unsigned p = (unsigned)(i >> 6);
+    const unsigned k0 = links[i], k1 = links[n + i];
+    if (k0 == NO_CHILD && k1 == NO_CHILD) return;
+    V3 sum = mk(terms[i], terms[n + i], terms[2 * n + i]);
+    if (k0 != NO_CHILD) {
+        const size_t j = (size_t)offsets[p] + k0;
+        sum = sum + mk(child[j], child[child_n + j], child[2 * child_n + j]);
+    }
+    if (k1 != NO_CHILD) {
+        const size_t j = (size_t)offsets[waves] + offsets[waves + 1u + p] + k1;
+        sum = sum + mk(child[j], child[child_n + j], child[2 * child_n + j]);
+    }
+    terms[i] = sum.x;
+    terms[n + i] = sum.y;
+    terms[2 * n + i] = sum.z;
+}
+
+// The finished sums of level 0 are the pixels: Canvas::write_pixel per tile, as render_kernel does it.
+__global__ __launch_bounds__(64) void level_store_kernel(RtCameraDev cam, RowMap rows, const double *__restrict__ terms, uint32_t waves, uint32_t blocks_x,
+                                                         double *__restrict__ rgb) {
+    __shared__ double staging[192];
+    const unsigned lane = threadIdx.x & 63, wave = blockIdx.x;
+    const unsigned tiles_x = (cam.hsize + 7) >> 3, tiles_y = (rows.n_rows + 7) >> 3;
+    unsigned tile;
+    if (!level0_tile(wave, blocks_x, tiles_x, tiles_y, tile)) return;
+    const unsigned x = (tile % tiles_x) * 8 + (lane & 7);
+    const unsigned r = (tile / tiles_x) * 8 + (lane >> 3);
+    const unsigned y = image_row(rows, r);
+    const bool valid = x < cam.hsize && r < rows.n_rows && y < rows.row_end;
+    const size_t n = (size_t)waves * 64, i = (size_t)wave * 64 + lane;
+    const V3 acc = mk(terms[i], terms[n + i], terms[2 * n + i]);
+    store_tile(cam, rows, tile, lane, valid, x, r, y, acc, staging, rgb);
+}
+
+hipError_t reserve(ArenaBuffer &b, size_t bytes) {
+    if (b.bytes >= bytes) return hipSuccess;
+    if (b.p) {
+        hipError_t e = hipFree(b.p);  // (waits for the device: nothing in flight reads it afterwards)
+        b.p = nullptr;
+        b.bytes = 0;
+        if (e != hipSuccess) return e;
+    }
+    const size_t grown = bytes + bytes / 8;  // a little room, so that a slightly larger frame does not allocate again
+    hipError_t e = hipMalloc(&b.p, grown);
+    if (e != hipSuccess) return e;
+    b.bytes = grown;
+    return hipSuccess;
+}
+
+template <int NEST, bool TIES>
+hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows, int max_depth, double *rgb, LevelArena &A,
+                         hipStream_t stream) {
+#define RT_TRY(expr)                       \
+    do {                                   \
+        hipError_t rt_try_e = (expr);      \
+        if (rt_try_e != hipSuccess) return rt_try_e; \
+    } while (0)
+    if (max_depth < 0 || max_depth >= LEVELS_MAX) return hipErrorInvalidValue;
+    const unsigned tiles_x = (camera.hsize + 7) / 8, tiles_y = (rows.n_rows + 7) / 8;
+    const unsigned blocks_x = (tiles_x + 7) / 8, blocks_y = (tiles_y + 7) / 8;
+    if ((unsigned long long)blocks_x * blocks_y * 64 > 0x00ffffffull) return hipErrorInvalidValue;  // 2^24 waves: 2^31 queue slots
+    if (!A.host_totals) RT_TRY(hipHostMalloc((void **)&A.host_totals, 2 * sizeof(uint32_t), 0));
+    const size_t lds = lds_bytes<NEST, false>(64);
+    unsigned waves = blocks_x * blocks_y * 64, n_rays = waves * 64, levels = 0;
+    uint32_t level_waves[LEVELS_MAX] = {};
+    for (int level = 0; level <= max_depth; ++level) {
+        const int out = level & 1, in = out ^ 1;
+        const bool last = level == max_depth;  // its rays have no budget left: nothing is appended
+        RT_TRY(reserve(A.terms[level], (size_t)waves * 64 * 3 * sizeof(double)));
+        RT_TRY(reserve(A.links[level], (size_t)waves * 64 * 2));
+        RT_TRY(reserve(A.counts, ((size_t)waves + 1) * 2 * sizeof(uint32_t)));
+        if (!last) {
+            RT_TRY(reserve(A.queue_f[out], (size_t)waves * 128 * 7 * sizeof(double)));
+            RT_TRY(reserve(A.queue_rem[out], (size_t)waves * 128));
+            RT_TRY(reserve(A.offsets[level], ((size_t)waves + 1) * 2 * sizeof(uint32_t)));
+        }
+        LevelIO io;
+        io.in_f = (const double *)A.queue_f[in].p;
+        io.in_rem = (const uint8_t *)A.queue_rem[in].p;
+        io.in_slots = level == 0 ? 0 : (size_t)level_waves[level - 1] * 128;
+        io.in_index = (const uint32_t *)A.index.p;
+        io.n_rays = n_rays;
+        io.out_f = (double *)A.queue_f[out].p;
+        io.out_rem = (uint8_t *)A.queue_rem[out].p;
+        io.out_counts = (uint32_t *)A.counts.p;
+        io.waves = waves;
+        io.terms = (double *)A.terms[level].p;
+        io.links = (uint8_t *)A.links[level].p;
+        io.blocks_x = blocks_x;
+        level_waves[level] = waves;
+        A.level_rays[level] = n_rays;
+        levels = level + 1;
+        if (level == 0) level_kernel<NEST, TIES, true><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
+        else level_kernel<NEST, TIES, false><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
+        RT_TRY(hipGetLastError());
+        if (last) break;
+        // number the children: reflections first, then refractions, each in the order of their parent waves
+        uint32_t *counts = (uint32_t *)A.counts.p, *offsets = (uint32_t *)A.offsets[level].p;
+        size_t need = 0;
+        RT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, counts, offsets, (int)(waves + 1), stream));
+        RT_TRY(reserve(A.scan_temp, need));
+        // (entry `waves` of each half of `counts` is never written by the kernel and must read as zero)
+        RT_TRY(hipMemsetAsync(counts + waves, 0, sizeof(uint32_t), stream));
+        RT_TRY(hipMemsetAsync(counts + 2 * (size_t)waves + 1, 0, sizeof(uint32_t), stream));
+        for (unsigned kind = 0; kind < 2; ++kind) {
+            size_t bytes = A.scan_temp.bytes;
+            RT_TRY(hipcub::DeviceScan::ExclusiveSum(A.scan_temp.p, bytes, counts + kind * ((size_t)waves + 1), offsets + kind * ((size_t)waves + 1),
+                                                    (int)(waves + 1), stream));
+        }
+        RT_TRY(hipMemcpyAsync(A.host_totals, offsets + waves, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        RT_TRY(hipMemcpyAsync(A.host_totals + 1, offsets + 2 * (size_t)waves + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        RT_TRY(hipStreamSynchronize(stream));
+        const unsigned long long children = (unsigned long long)A.host_totals[0] + A.host_totals[1];
+        if (children == 0) break;
+        if (children > 0x3fffffffull) return hipErrorOutOfMemory;
+        RT_TRY(reserve(A.index, (size_t)children * sizeof(uint32_t)));
+        level_index_kernel<<<dim3((unsigned)(((size_t)waves * 128 + 255) / 256)), 256, 0, stream>>>(counts, offsets, waves, (uint32_t *)A.index.p);
+        n_rays = (unsigned)children;
+        waves = (n_rays + 63) / 64;
+    }
+    for (int level = (int)levels - 2; level >= 0; --level) {
+        const unsigned w = level_waves[level];
+        level_sum_kernel<<<dim3((A.level_rays[level] + 255) / 256), 256, 0, stream>>>((double *)A.terms[level].p, (const uint8_t *)A.links[level].p,
+                                                                                     (const uint32_t *)A.offsets[level].p, w, A.level_rays[level],
+                                                                                     (const double *)A.terms[level + 1].p, (size_t)level_waves[level + 1] * 64);
+    }
+    level_store_kernel<<<dim3(level_waves[0]), 64, 0, stream>>>(camera, rows, (const double *)A.terms[0].p, level_waves[0], blocks_x, rgb);
+    A.levels = levels;
+    return hipGetLastError();
+#undef RT_TRY
+}
+
+}  // namespace
+
+size_t LevelArena::device_bytes() const {
+    size_t total = queue_f[0].bytes + queue_f[1].bytes + queue_rem[0].bytes + queue_rem[1].bytes + counts.bytes + index.bytes + scan_temp.bytes;
+    for (int k = 0; k < LEVELS_MAX; ++k) total += offsets[k].bytes + terms[k].bytes + links[k].bytes;
+    return total;
+}
+
+void level_arena_release(LevelArena &A) {
+    auto drop = [](ArenaBuffer &b) {
+        if (b.p) (void)hipFree(b.p);
+        b = ArenaBuffer();
+    };
+    for (int k = 0; k < 2; ++k) drop(A.queue_f[k]), drop(A.queue_rem[k]);
+    drop(A.counts), drop(A.index), drop(A.scan_temp);
+    for (int k = 0; k < LEVELS_MAX; ++k) drop(A.offsets[k]), drop(A.terms[k]), drop(A.links[k]);
+    if (A.host_totals) (void)hipHostFree(A.host_totals);
+    A.host_totals = nullptr;
+    A.levels = 0;
+}
+
+hipError_t launch_render_levels(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows_in, int max_depth, double *rgb,
+                                LevelArena &arena, hipStream_t stream, hipEvent_t *marks) {
+    if (rows_in.n_rows == 0 || camera.hsize == 0 || rows_in.band_rows == 0) return hipSuccess;
+    if (scene.max_nesting == 0) return hipErrorInvalidValue;
+    RowMap rows = rows_in;
+    rows.n_tiles = ((camera.hsize + 7) / 8) * ((rows.n_rows + 7) / 8);
+    rows.tile_list = nullptr;
+    if (marks) {
+        hipError_t e = hipEventRecord(marks[0], stream);
+        if (e == hipSuccess) e = hipEventRecord(marks[1], stream);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e;
+    if (scene.any_order != 0 && scene.cone_nodes == 0) e = render_levels<2, true>(scene, camera, rows, max_depth, rgb, arena, stream);
+    else if (scene.any_order != 0) e = render_levels<1, true>(scene, camera, rows, max_depth, rgb, arena, stream);
+    else e = render_levels<1, false>(scene, camera, rows, max_depth, rgb, arena, stream);
+    if (e == hipSuccess && marks) e = hipEventRecord(marks[2], stream);
+    return e;
+}

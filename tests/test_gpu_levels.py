@@ -1,0 +1,189 @@
+"""Worlds rendered level by level of their ray trees (rt_scene_info.kernel_build 3): the path large hierarchies take by
+default, forced here (RT_RENDER_LEVELS=1, read when a scene is created) onto every kind of world with groups the suite
+has, so that its queues, its numbering of rays and its sums are held to the oracle on nested groups, cones under
+range-skip nodes, reordered sibling lists and ties -- not only on the one generated scene that takes it by itself."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_frames_match, counters_equal, load_both, scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def levels(monkeypatch):
+    monkeypatch.setenv("RT_RENDER_LEVELS", "1")
+
+
+def _hip():
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    return hip
+
+
+def _fetch(hip, ptr, shape, dtype):
+    out = np.zeros(shape, dtype=dtype)
+    assert hip.hipDeviceSynchronize() == 0
+    assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), ptr, out.nbytes, 2) == 0
+    return out
+
+
+@pytest.mark.parametrize("scene", ["chapter_12", "chapter_14"])
+def test_book_scenes_with_groups_level_by_level(gpu, rt, orc, levels, scene):
+    cam, world, ocam, oworld = load_both(rt, orc, scene)
+    s = world.scene()
+    assert s.info().kernel_build == 3
+    plain, _ = s.render(cam)
+    counted, st = s.render(cam, stats=True)  # (the counting kernel stays the single launch)
+    oc = orc.Counters()
+    ref = orc.render(ocam, oworld, threads=16, counters=oc)
+    assert_frames_match(orc, plain, ref)
+    counters_equal(st, oc)
+    assert np.abs(plain - counted).max() <= 1e-13
+    again, _ = s.render(cam)
+    assert np.array_equal(again, plain), "two renders of the same frame differ"
+
+
+@pytest.mark.parametrize("seed,n_top", [(1, 6), (4, 6), (9, 6), (12, 6), (101, 25), (103, 60), (104, 90)])
+def test_random_worlds_level_by_level(gpu, rt, orc, levels, seed, n_top):
+    """Random hierarchies (every shape, cones under range-skip nodes, nested groups, patterns, glass and mirrors)."""
+    import tomli
+
+    from raytracer_rs_amd import synthetic
+
+    text = synthetic.random_scene(seed, 96, 64, n_top)
+    sf = rt.SceneFile.from_str(text)
+    cam, world = sf.build_camera(), sf.build_world()
+    s = world.scene()
+    if s.info().max_nesting == 0:
+        pytest.skip("this seed has no groups: the single launch serves it whatever the environment says")
+    assert s.info().kernel_build == 3
+    ocam, oworld = orc.scene_from_dict(tomli.loads(text))
+    plain, _ = s.render(cam)
+    ref = orc.render(ocam, oworld, threads=8)
+    assert_frames_match(orc, plain, ref)
+
+
+def test_every_way_to_cut_a_frame_gives_the_same_bits(gpu, rt, orc, levels):
+    """Level by level a pixel's colour is a function of its own ray tree alone: whole frame, row ranges on and OFF the
+    8-row tile grid, bands, rows stored in place, the 8-bit frame and the host frame all carry the same values."""
+    hip = _hip()
+    w, h = 403, 277
+    cam, world, _, _ = load_both(rt, orc, "chapter_14", w, h)
+    s = world.scene()
+    full, _ = s.render(cam)
+    work = np.zeros_like(full)
+    for rows in ((0, 8), (3, 20), (101, 102), (270, 277), (16, 200)):
+        s.render(cam, rows=rows, out=work)
+        assert np.array_equal(work[rows[0]:rows[1]], full[rows[0]:rows[1]]), rows
+    work.fill(0.0)
+    for r in range(3):
+        s.render(cam, bands=(16, r, 3), out=work)
+    assert np.array_equal(work, full)
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), full.nbytes + 64) == 0
+    try:
+        assert hip.hipMemset(buf, 0xA5, full.nbytes + 64) == 0
+        s.render_device(cam, buf.value)
+        got = _fetch(hip, buf, full.nbytes + 64, np.uint8)
+        assert np.array_equal(got[:full.nbytes].view(np.float64).reshape(full.shape), full)
+        assert (got[full.nbytes:] == 0xA5).all(), "wrote past the frame"
+        # stripes 1, 4, 7, ... of 16 rows, stored at their own rows of a whole frame
+        assert hip.hipMemset(buf, 0, full.nbytes) == 0
+        s.render_device_bands(cam, buf.value, 16, 1, 3, in_place=True)
+        got = _fetch(hip, buf, full.shape, np.float64)
+        for k in range((h + 15) // 16):
+            rows = slice(16 * k, min(h, 16 * k + 16))
+            want = full[rows] if k % 3 == 1 else np.zeros_like(full[rows])
+            assert np.array_equal(got[rows], want), k
+        # the 8-bit frame
+        assert hip.hipMemset(buf, 0xA5, w * h * 3 + 64) == 0
+        s.render_device(cam, buf.value, quantized=True)
+        q = _fetch(hip, buf, w * h * 3 + 64, np.uint8)
+        assert np.array_equal(q[:w * h * 3].reshape(h, w, 3), orc.quantize(full))
+        assert (q[w * h * 3:] == 0xA5).all(), "wrote past the 8-bit frame"
+    finally:
+        hip.hipFree(buf)
+
+
+def test_several_workers_level_by_level(gpu, rt, orc, levels):
+    """rt_multi_* over a world rendered level by level: workers, units and stripes as for any world; the frame is the
+    single-handle frame bit for bit (f64 in device memory, 8-bit, host), the counters are the counting kernel's."""
+    hip = _hip()
+    w, h = 320, 203
+    cam, world, _, _ = load_both(rt, orc, "chapter_14", w, h)
+    full, _ = world.scene().render(cam)
+    _, st_full = world.scene().render(cam, stats=True)
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), full.nbytes) == 0
+    try:
+        for devices, band_rows, units in (([0, 0], 0, 0), ([0, 0, 0], 8, 5), ([0], 24, 0)):
+            multi = world.multi_scene(devices)
+            multi.render_device(cam, buf.value, band_rows=band_rows, units=units)
+            assert np.array_equal(_fetch(hip, buf, full.shape, np.float64), full), (devices, band_rows)
+            st = multi.render_device(cam, buf.value, band_rows=band_rows, stats=True, units=units)
+            assert st.as_dict() == st_full.as_dict()
+            multi.render_device(cam, buf.value, band_rows=band_rows, quantized=True, units=units)
+            assert np.array_equal(_fetch(hip, buf, (h, w, 3), np.uint8), orc.quantize(full))
+            host, _ = multi.render(cam, band_rows=band_rows, units=units)
+            assert np.array_equal(host, full)
+            multi.close()
+    finally:
+        hip.hipFree(buf)
+
+
+def test_noalloc_entry_point_refuses_worlds_rendered_by_levels(gpu, rt, orc, levels):
+    cam, world, _, _ = load_both(rt, orc, "chapter_14", 64, 48)
+    with pytest.raises(rt.RtError) as e:
+        world.scene().render_device_noalloc(cam, 4096)  # refused before anything is launched: the pointer is never used
+    assert e.value.code == -7 and "level by level" in e.value.message
+
+
+def test_deep_trees_and_empty_levels(gpu, rt, orc, levels):
+    """Budgets from 0 (one level, nothing appended) to the library's maximum of 8 (nine levels), a world nothing in which
+    reflects (level 1 is empty), and a frame smaller than one block of tiles."""
+    import tomli
+
+    w, h = 72, 48
+    cam, world, ocam, oworld = load_both(rt, orc, "chapter_14", w, h)
+    s = world.scene()
+    px = [x for y in range(h) for x in range(w)]
+    py = [y for y in range(h) for x in range(w)]
+    rays = np.array([list(r.origin) + list(r.direction) for r in cam.rays_for_pixels(px, py)])
+    for depth in (0, 1, 8):
+        img, _ = s.render(cam, max_depth=depth)
+        ref = np.array([oworld.color_at(orc.ray(r[:3], r[3:]), depth) for r in rays]).reshape(h, w, 3)
+        assert np.abs(img - ref).max() <= 1e-12, depth
+    text = """
+[camera]
+width = 24
+height = 17
+fov = 60.0
+from = [0.0, 1.5, -5.0]
+to = [0.0, 1.0, 0.0]
+up = [0.0, 1.0, 0.0]
+[light]
+position = [-10.0, 10.0, -10.0]
+intensity = [1.0, 1.0, 1.0]
+[[objects]]
+type = "group"
+[[objects.children]]
+type = "sphere"
+[objects.children.material]
+color = [0.9, 0.2, 0.2]
+[[objects.children]]
+type = "cube"
+[objects.children.transform]
+translate = [2.0, 0.0, 1.0]
+"""
+    sf = rt.SceneFile.from_str(text)
+    cam, world = sf.build_camera(), sf.build_world()
+    assert world.scene().info().kernel_build == 3
+    img, _ = world.scene().render(cam)
+    ocam, oworld = orc.scene_from_dict(tomli.loads(text))
+    assert_frames_match(orc, img, orc.render(ocam, oworld, threads=4))

@@ -43,6 +43,23 @@ def counters_equal(stats, counters):
     assert stats.as_dict() == counters.as_dict()
 
 
+def by_levels(scene):
+    """The world is rendered level by level of its ray trees (rt_scene_info.kernel_build 3: large hierarchies, or
+    RT_RENDER_LEVELS=1 when the scene was created) instead of by one launch."""
+    return scene.info().kernel_build == 3
+
+
+def assert_kernels_agree(scene, plain, counted):
+    """The counting kernel -- always the single launch, it visits what the reference visits -- and the plain path render
+    the same frame: bit for bit when the plain path is the single launch too; within 1e-13 when the world is rendered
+    level by level, where a ray's term is added to its parent's sum (reflection, then refraction) instead of to a
+    running sum in the order the rays are walked."""
+    if by_levels(scene):
+        assert np.abs(plain - counted).max() <= 1e-13, "counting and plain kernels disagree"
+    else:
+        assert np.array_equal(plain, counted), "counting and plain kernels disagree"
+
+
 def load_both(rt, orc, scene, width=None, height=None):
     sf = rt.SceneFile.from_file(scene_path(scene))
     cam = sf.build_camera(width, height)
@@ -60,7 +77,8 @@ def test_scene_matches_oracle(gpu, rt, orc, scene):
     assert_frames_match(orc, img, ref)
     counters_equal(st, oc)
     plain, _ = world.scene().render(cam)
-    assert np.array_equal(plain, img), "counting and plain kernels disagree"
+    assert_frames_match(orc, plain, ref)
+    assert_kernels_agree(world.scene(), plain, img)
 
 
 @pytest.mark.parametrize("scene,image", PPM_PAIRS)
@@ -390,7 +408,8 @@ def test_random_scene_matches_oracle(gpu, rt, orc, seed, n_top):
     assert_frames_match(orc, img, ref)
     counters_equal(st, oc)
     plain, _ = world.scene().render(cam)
-    assert np.array_equal(plain, img), "counting and plain kernels disagree"
+    assert_frames_match(orc, plain, ref)
+    assert_kernels_agree(world.scene(), plain, img)
 
 
 def test_large_generated_scene_matches_oracle(gpu, rt, orc):
@@ -410,9 +429,12 @@ def test_large_generated_scene_matches_oracle(gpu, rt, orc):
     ref = orc.render(ocam, oworld, threads=16, counters=oc)
     assert_frames_match(orc, img, ref)
     counters_equal(st, oc)
-    # the plain kernel steps over runs of nodes no ray of a wave can touch; the counting kernel visits everything
+    # the plain path steps over runs of nodes no ray of a wave can touch, and renders a hierarchy of this size level by
+    # level; the counting kernel visits everything, in one launch
+    assert info.kernel_build == 3
     plain, _ = world.scene().render(cam)
-    assert np.array_equal(plain, img), "counting and plain kernels disagree"
+    assert_frames_match(orc, plain, ref)
+    assert_kernels_agree(world.scene(), plain, img)
 
 
 def _lone_rays_agree(orc, scene, oworld, rays):
@@ -852,8 +874,9 @@ def test_groups_nested_twelve_deep(gpu, rt, orc):
     plain, _ = scene.render(cam)
     oc = orc.Counters()
     ref = orc.render(ocam, oworld, threads=8, counters=oc)
-    assert np.array_equal(plain, img)
+    assert_kernels_agree(scene, plain, img)
     assert_frames_match(orc, img, ref)
+    assert_frames_match(orc, plain, ref)
     counters_equal(st, oc)
     assert st.reflect > 0 and st.refract > 0 and st.aabb_tests > 12 * 96 * 64 // 8
     rays = _probe_rays(orc, ocam, 31, 200, 200, ((-4, -1, -4), (6, 5, 4)))
@@ -1150,15 +1173,27 @@ def test_full_4k_frame(gpu, rt, orc):
     assert np.array_equal(acc, img)
 
 
-def test_which_build_of_the_render_kernel_serves_which_world(gpu, rt):
+def test_which_build_of_the_render_kernel_serves_which_world(gpu, rt, monkeypatch):
     """rt_scene_info.kernel_build: a table of leaves for the book's flat scenes, the build without cone directions for
-    chapter_14 (groups, spheres and cylinders), the general one for the generated hierarchy (cones under its
-    range-skip nodes)."""
+    chapter_14 (groups, spheres and cylinders), the general one for hierarchies with cones under their range-skip
+    nodes, and level-by-level rendering for the generated hierarchy of 10 001 leaves.  RT_RENDER_LEVELS in the
+    environment, read when a scene is created, overrides the choice between single launch and levels for worlds with
+    groups."""
     from raytracer_rs_amd import synthetic
 
-    assert rt.SceneFile.from_file(scene_path("chapter_11")).build_world().scene().info().kernel_build == 0
-    assert rt.SceneFile.from_file(scene_path("chapter_14")).build_world().scene().info().kernel_build == 2
-    assert rt.SceneFile.from_str(synthetic.large_scene(64, 36)).build_world().scene().info().kernel_build == 1
+    def build(world):
+        k = world.scene().info().kernel_build
+        world.release_scene()
+        return k
+
+    ch11 = rt.SceneFile.from_file(scene_path("chapter_11")).build_world()
+    ch14 = rt.SceneFile.from_file(scene_path("chapter_14")).build_world()
+    large = rt.SceneFile.from_str(synthetic.large_scene(64, 36)).build_world()
+    assert (build(ch11), build(ch14), build(large)) == (0, 2, 3)
+    monkeypatch.setenv("RT_RENDER_LEVELS", "0")
+    assert (build(ch11), build(ch14), build(large)) == (0, 2, 1)
+    monkeypatch.setenv("RT_RENDER_LEVELS", "1")
+    assert (build(ch11), build(ch14), build(large)) == (0, 3, 3)
 
 
 def test_full_hd_world_with_shadows(gpu, rt, orc):
@@ -1179,31 +1214,38 @@ def test_full_hd_world_with_shadows(gpu, rt, orc):
 
 def _full_size_checks(orc, scene, cam, ocam, oworld, n_sample_bands, band_rows=4):
     """What can be checked on a frame too large for the oracle to render whole: row bands spread over the frame
-    against the oracle (colours and, for the same rows, every counter); the counting and the plain kernel agree on
-    all of it; the ray count adds up; 16-row bands dealt to 8 ranks reassemble the frame."""
+    against the oracle (colours and, for the same rows, every counter), of the counting kernel's frame and of the plain
+    path's; the two agree on all of it; the ray count adds up; 16-row bands dealt to 8 ranks reassemble the frame."""
     h, w = cam.vsize, cam.hsize
-    img, st = scene.render(cam, stats=True)
+    counted, st = scene.render(cam, stats=True)
     plain, _ = scene.render(cam)
-    assert np.array_equal(plain, img), "counting and plain kernels disagree"
+    assert_kernels_agree(scene, plain, counted)
     assert st.primary == w * h and st.rays == st.primary + st.shadow + st.reflect + st.refract
+    work = plain.copy()
     for k in range(n_sample_bands):
         y0 = ((h - band_rows) * k // (n_sample_bands - 1)) // band_rows * band_rows
         oc = orc.Counters()
         ref = orc.render(ocam, oworld, threads=16, rows=(y0, y0 + band_rows), counters=oc)
-        assert_frames_match(orc, img[y0:y0 + band_rows], ref[y0:y0 + band_rows])
+        assert_frames_match(orc, counted[y0:y0 + band_rows], ref[y0:y0 + band_rows])
+        assert_frames_match(orc, plain[y0:y0 + band_rows], ref[y0:y0 + band_rows])
         del ref
-        _, pst = scene.render(cam, rows=(y0, y0 + band_rows), stats=True, out=plain)  # rows of the whole-frame buffer
+        _, pst = scene.render(cam, rows=(y0, y0 + band_rows), stats=True, out=work)  # rows of the whole-frame buffer
         counters_equal(pst, oc)
-        # Rows that do not start and end on the 8-row tile grid put a pixel in a tile with other neighbours; in scenes
-        # with groups lanes hand rays to each other, so the terms of a pixel's sum may then be added in another order.
-        assert np.abs(plain[y0:y0 + band_rows] - img[y0:y0 + band_rows]).max() <= 1e-13
+        scene.render(cam, rows=(y0, y0 + band_rows), out=work)
+        if by_levels(scene):
+            # level by level a pixel's colour is a function of its own ray tree: any rows, the same bits
+            assert np.array_equal(work[y0:y0 + band_rows], plain[y0:y0 + band_rows])
+        else:
+            # Rows that do not start and end on the 8-row tile grid put a pixel in a tile with other neighbours; in
+            # scenes with groups lanes hand rays to each other, so the terms of a pixel's sum may be added in another order.
+            assert np.abs(work[y0:y0 + band_rows] - plain[y0:y0 + band_rows]).max() <= 1e-13
         t0 = y0 // 8 * 8
-        scene.render(cam, rows=(t0, t0 + 8), out=plain)
-        assert np.array_equal(plain[t0:t0 + 8], img[t0:t0 + 8])
-    plain.fill(0.0)
+        scene.render(cam, rows=(t0, t0 + 8), out=work)
+        assert np.array_equal(work[t0:t0 + 8], plain[t0:t0 + 8])
+    work.fill(0.0)
     for r in range(8):
-        scene.render(cam, bands=(16, r, 8), out=plain)
-    assert np.array_equal(plain, img)
+        scene.render(cam, bands=(16, r, 8), out=work)
+    assert np.array_equal(work, plain)
 
 
 def test_full_4k_hexagon_groups(gpu, rt, orc):
