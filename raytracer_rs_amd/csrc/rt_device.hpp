@@ -48,9 +48,9 @@ struct ArenaBuffer {
 constexpr int LEVELS_MAX = RT_MAX_DEPTH + 1;  // level 0 = the rays through the pixels, level k = their k-th generation of children
 struct LevelArena {
     ArenaBuffer queue_f[2], queue_rem[2];  // the rays a level reads and the rays it writes (origin, direction, weight; remaining budget)
-    ArenaBuffer counts;                    // children per wave and kind of the level being rendered
-    ArenaBuffer offsets[LEVELS_MAX];       // the same, scanned: where a wave's children stand in the next level (kept for the sums)
+    ArenaBuffer counts, offsets;           // children per bin and wave of the level being rendered, and the same scanned
     ArenaBuffer index;                     // ray number in the next level -> its slot in the queue
+    ArenaBuffer ray_of_slot[LEVELS_MAX];   // the other way round, per level (kept for the sums: where a ray's children are)
     ArenaBuffer terms[LEVELS_MAX];         // per ray of a level: its term of its pixel's sum, then the sum over its subtree
     ArenaBuffer links[LEVELS_MAX];         // per ray of a level: which of its wave's children are its own
     ArenaBuffer scan_temp;

@@ -11,11 +11,12 @@
 //                both directions): ray through the pixel, closest hit, shading, shadow ray;
 //   level k > 0  one wave per 64 consecutive rays of the queue the level before wrote.
 //
-// A wave writes the reflection and refraction rays it spawns into slots of its own (64 per kind), counts them, and an
-// exclusive scan of the counts numbers the next level's rays: all reflections first, then all refractions, each in the
-// order of their parent waves -- screen order, roughly, at every level, so a wave's 64 rays are of one kind and from
-// neighbouring pixels.  (Appending in the order in which waves happen to finish mixes rays from all over the frame:
-// measured, the deeper levels then take three to four times as long.)
+// A wave writes the reflection and refraction rays it spawns into slots of its own (64 per kind), counts them per
+// BIN -- kind x octant of the ray's direction, sixteen bins -- and an exclusive scan of the counts numbers the next
+// level's rays: bin after bin, each bin in the order of the parent waves -- screen order, roughly, at every level --
+// so a wave's 64 rays are of one kind, travel in one octant (the node tables are ordered front to back per octant)
+// and come from neighbouring pixels.  (Appending in the order in which waves happen to finish mixes rays from all over
+// the frame: measured, the deeper levels then take three to four times as long.)
 //
 // Sums.  Each ray stores its term of its pixel's colour (path weight x surface colour, as in radiance()) under its own
 // number and remembers which of its wave's children are its own; when the last level is done, one pass per level,
@@ -32,6 +33,7 @@
 namespace {
 
 constexpr unsigned NO_CHILD = 0xffu;
+constexpr unsigned LEVEL_BINS = 16;  // kind (reflection, refraction) x octant of the direction (bit a set: towards -a, as DeviceScene::oct_tables)
 
 struct LevelIO {
     // the rays of this level (unused at level 0)
@@ -43,7 +45,7 @@ struct LevelIO {
     // what it writes
     double *out_f = nullptr;            // 128 slots per wave: kind * 64 * waves + wave * 64 + k
     uint8_t *out_rem = nullptr;
-    uint32_t *out_counts = nullptr;     // [2][waves + 1]
+    uint32_t *out_counts = nullptr;     // [LEVEL_BINS][waves + 1]: children per bin (kind * 8 + octant) and wave
     uint32_t waves = 0;
     double *terms = nullptr;            // three arrays of 64 * waves doubles
     uint8_t *links = nullptr;           // two arrays of 64 * waves bytes: k of the ray's reflection / refraction, or NO_CHILD
@@ -94,17 +96,25 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES(NEST)) void level_kernel(DeviceS
     const size_t out_slots = (size_t)io.waves * 128;
     if (FIRST && __ballot(have) == 0ull) {  // a tile outside the frame (the launch is padded to whole blocks of tiles)
         const size_t n = (size_t)io.waves * 64, i = (size_t)wave * 64 + lane;
-        if (lane < 2) io.out_counts[lane * (io.waves + 1u) + wave] = 0u;
+        if (lane < LEVEL_BINS) io.out_counts[lane * (io.waves + 1u) + wave] = 0u;
         io.terms[i] = 0.0, io.terms[n + i] = 0.0, io.terms[2 * n + i] = 0.0;
         io.links[i] = (uint8_t)NO_CHILD, io.links[n + i] = (uint8_t)NO_CHILD;
         return;
     }
-    // The wave's children of one kind, packed into its 64 slots for that kind; returns the lane's k (NO_CHILD if none).
+    // The wave's children of one kind, packed into its 64 slots for that kind, octant after octant; returns the lane's k
+    // (NO_CHILD if none).
     auto append = [&](bool want, unsigned kind, V3 o, V3 d, double pw, int prem) -> unsigned {
-        const unsigned long long m = __ballot(want);
-        if (lane == 0) io.out_counts[kind * (io.waves + 1u) + wave] = (unsigned)__popcll(m);
+        const unsigned oct = (d.x < 0.0 ? 1u : 0u) | (d.y < 0.0 ? 2u : 0u) | (d.z < 0.0 ? 4u : 0u);
+        unsigned k = 0, before = 0;
+#pragma unroll
+        for (unsigned b = 0; b < 8; ++b) {
+            const unsigned long long m = __ballot(want && oct == b);
+            const unsigned n = (unsigned)__popcll(m);
+            if (lane == b) io.out_counts[(kind * 8u + b) * (io.waves + 1u) + wave] = n;
+            if (oct == b) k = before + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            before += n;
+        }
         if (!want) return NO_CHILD;
-        const unsigned k = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         const size_t slot = (size_t)kind * 64 * io.waves + (size_t)wave * 64 + k;
         double *f = io.out_f + slot;
         f[0] = o.x, f[out_slots] = o.y, f[2 * out_slots] = o.z;
@@ -203,36 +213,43 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES(NEST)) void level_kernel(DeviceS
     io.links[n + i] = (uint8_t)k_refract;
 }
 
-// Ray number in the next level -> queue slot: child k of kind `kind` of parent wave p is ray
-// (kind ? all reflections : 0) + offsets[kind][p] + k and lies in slot kind * 64 * waves + p * 64 + k.
-__global__ __launch_bounds__(256) void level_index_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets, uint32_t waves,
-                                                          uint32_t *__restrict__ index) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)waves * 128) return;
-    const unsigned kind = t >= (size_t)waves * 64 ? 1u : 0u;
-    const unsigned p = (unsigned)((t - (size_t)kind * 64 * waves) >> 6), k = (unsigned)(t & 63u);
-    if (k >= counts[kind * (waves + 1u) + p]) return;
-    const unsigned first = kind ? offsets[waves] : 0u;
-    index[first + offsets[kind * (waves + 1u) + p] + k] = (uint32_t)t;
+// Numbers the children of one level: child k of kind `kind` of parent wave p lies in slot kind * 64 * waves + p * 64 + k;
+// its bin is the octant whose run of p's block holds k, and its number in the next level is the scanned count of
+// (bin, p) plus its place in that run.  Writes both directions of the mapping.  One wave per (parent, kind).
+__global__ __launch_bounds__(64) void level_index_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets, uint32_t waves,
+                                                         uint32_t *__restrict__ slot_of_ray, uint32_t *__restrict__ ray_of_slot) {
+    const unsigned kind = blockIdx.x >= waves ? 1u : 0u, p = blockIdx.x - kind * waves, k = threadIdx.x;
+    unsigned before = 0;
+    for (unsigned b = 0; b < 8; ++b) {
+        const size_t at = (size_t)(kind * 8u + b) * (waves + 1u) + p;
+        const unsigned n = counts[at];
+        if (k >= before && k < before + n) {
+            const size_t slot = (size_t)kind * 64 * waves + (size_t)p * 64 + k;
+            const uint32_t ray = offsets[at] + (k - before);
+            slot_of_ray[ray] = (uint32_t)slot;
+            ray_of_slot[slot] = ray;
+        }
+        before += n;
+    }
 }
 
 // Children before parents: a ray's sum = its own term + the sum of its reflection + the sum of its refraction
 // (the order of world.rs:107-110).  `child` holds the finished sums of the next level.
-__global__ __launch_bounds__(256) void level_sum_kernel(double *__restrict__ terms, const uint8_t *__restrict__ links, const uint32_t *__restrict__ offsets,
+__global__ __launch_bounds__(256) void level_sum_kernel(double *__restrict__ terms, const uint8_t *__restrict__ links, const uint32_t *__restrict__ ray_of_slot,
                                                         uint32_t waves, uint32_t n_rays, const double *__restrict__ child, size_t child_n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rays) return;
     const size_t n = (size_t)waves * 64;
-    const unsigned p = (unsigned)(i >> 6);
+    const size_t block = (i >> 6) * 64;
     const unsigned k0 = links[i], k1 = links[n + i];
     if (k0 == NO_CHILD && k1 == NO_CHILD) return;
     V3 sum = mk(terms[i], terms[n + i], terms[2 * n + i]);
     if (k0 != NO_CHILD) {
-        const size_t j = (size_t)offsets[p] + k0;
+        const size_t j = ray_of_slot[block + k0];
         sum = sum + mk(child[j], child[child_n + j], child[2 * child_n + j]);
     }
     if (k1 != NO_CHILD) {
-        const size_t j = (size_t)offsets[waves] + offsets[waves + 1u + p] + k1;
+        const size_t j = ray_of_slot[n + block + k1];
         sum = sum + mk(child[j], child[child_n + j], child[2 * child_n + j]);
     }
     terms[i] = sum.x;
@@ -284,6 +301,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
     const unsigned tiles_x = (camera.hsize + 7) / 8, tiles_y = (rows.n_rows + 7) / 8;
     const unsigned blocks_x = (tiles_x + 7) / 8, blocks_y = (tiles_y + 7) / 8;
     if ((unsigned long long)blocks_x * blocks_y * 64 > 0x00ffffffull) return hipErrorInvalidValue;  // 2^24 waves: 2^31 queue slots
+    if ((unsigned long long)(blocks_x * blocks_y * 64 + 1) * LEVEL_BINS > 0x7fffffffull) return hipErrorInvalidValue;  // (the scan counts in int)
     if (!A.host_totals) RT_TRY(hipHostMalloc((void **)&A.host_totals, 2 * sizeof(uint32_t), 0));
     const size_t lds = lds_bytes<NEST, false>(64);
     unsigned waves = blocks_x * blocks_y * 64, n_rays = waves * 64, levels = 0;
@@ -293,11 +311,13 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         const bool last = level == max_depth;  // its rays have no budget left: nothing is appended
         RT_TRY(reserve(A.terms[level], (size_t)waves * 64 * 3 * sizeof(double)));
         RT_TRY(reserve(A.links[level], (size_t)waves * 64 * 2));
-        RT_TRY(reserve(A.counts, ((size_t)waves + 1) * 2 * sizeof(uint32_t)));
+        const size_t table = ((size_t)waves + 1) * LEVEL_BINS;  // per bin: one count per wave and a last entry that stays zero
+        RT_TRY(reserve(A.counts, table * sizeof(uint32_t)));
         if (!last) {
             RT_TRY(reserve(A.queue_f[out], (size_t)waves * 128 * 7 * sizeof(double)));
             RT_TRY(reserve(A.queue_rem[out], (size_t)waves * 128));
-            RT_TRY(reserve(A.offsets[level], ((size_t)waves + 1) * 2 * sizeof(uint32_t)));
+            RT_TRY(reserve(A.offsets, table * sizeof(uint32_t)));
+            RT_TRY(reserve(A.ray_of_slot[level], (size_t)waves * 128 * sizeof(uint32_t)));
         }
         LevelIO io;
         io.in_f = (const double *)A.queue_f[in].p;
@@ -315,38 +335,32 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         level_waves[level] = waves;
         A.level_rays[level] = n_rays;
         levels = level + 1;
+        uint32_t *counts = (uint32_t *)A.counts.p, *offsets = (uint32_t *)A.offsets.p;
+        if (!last) RT_TRY(hipMemsetAsync(counts, 0, table * sizeof(uint32_t), stream));  // (the last entry of every bin must read as zero)
         if (level == 0) level_kernel<NEST, TIES, true><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
         else level_kernel<NEST, TIES, false><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
         RT_TRY(hipGetLastError());
         if (last) break;
-        // number the children: reflections first, then refractions, each in the order of their parent waves
-        uint32_t *counts = (uint32_t *)A.counts.p, *offsets = (uint32_t *)A.offsets[level].p;
+        // number the children: bin after bin, each bin in the order of the parent waves
         size_t need = 0;
-        RT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, counts, offsets, (int)(waves + 1), stream));
+        RT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, counts, offsets, (int)table, stream));
         RT_TRY(reserve(A.scan_temp, need));
-        // (entry `waves` of each half of `counts` is never written by the kernel and must read as zero)
-        RT_TRY(hipMemsetAsync(counts + waves, 0, sizeof(uint32_t), stream));
-        RT_TRY(hipMemsetAsync(counts + 2 * (size_t)waves + 1, 0, sizeof(uint32_t), stream));
-        for (unsigned kind = 0; kind < 2; ++kind) {
-            size_t bytes = A.scan_temp.bytes;
-            RT_TRY(hipcub::DeviceScan::ExclusiveSum(A.scan_temp.p, bytes, counts + kind * ((size_t)waves + 1), offsets + kind * ((size_t)waves + 1),
-                                                    (int)(waves + 1), stream));
-        }
-        RT_TRY(hipMemcpyAsync(A.host_totals, offsets + waves, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        RT_TRY(hipMemcpyAsync(A.host_totals + 1, offsets + 2 * (size_t)waves + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        size_t bytes = A.scan_temp.bytes;
+        RT_TRY(hipcub::DeviceScan::ExclusiveSum(A.scan_temp.p, bytes, counts, offsets, (int)table, stream));
+        RT_TRY(hipMemcpyAsync(A.host_totals, offsets + table - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         RT_TRY(hipStreamSynchronize(stream));
-        const unsigned long long children = (unsigned long long)A.host_totals[0] + A.host_totals[1];
+        const unsigned long long children = A.host_totals[0];
         if (children == 0) break;
         if (children > 0x3fffffffull) return hipErrorOutOfMemory;
         RT_TRY(reserve(A.index, (size_t)children * sizeof(uint32_t)));
-        level_index_kernel<<<dim3((unsigned)(((size_t)waves * 128 + 255) / 256)), 256, 0, stream>>>(counts, offsets, waves, (uint32_t *)A.index.p);
+        level_index_kernel<<<dim3(2 * waves), 64, 0, stream>>>(counts, offsets, waves, (uint32_t *)A.index.p, (uint32_t *)A.ray_of_slot[level].p);
         n_rays = (unsigned)children;
         waves = (n_rays + 63) / 64;
     }
     for (int level = (int)levels - 2; level >= 0; --level) {
         const unsigned w = level_waves[level];
         level_sum_kernel<<<dim3((A.level_rays[level] + 255) / 256), 256, 0, stream>>>((double *)A.terms[level].p, (const uint8_t *)A.links[level].p,
-                                                                                     (const uint32_t *)A.offsets[level].p, w, A.level_rays[level],
+                                                                                     (const uint32_t *)A.ray_of_slot[level].p, w, A.level_rays[level],
                                                                                      (const double *)A.terms[level + 1].p, (size_t)level_waves[level + 1] * 64);
     }
     level_store_kernel<<<dim3(level_waves[0]), 64, 0, stream>>>(camera, rows, (const double *)A.terms[0].p, level_waves[0], blocks_x, rgb);
@@ -358,8 +372,8 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
 }  // namespace
 
 size_t LevelArena::device_bytes() const {
-    size_t total = queue_f[0].bytes + queue_f[1].bytes + queue_rem[0].bytes + queue_rem[1].bytes + counts.bytes + index.bytes + scan_temp.bytes;
-    for (int k = 0; k < LEVELS_MAX; ++k) total += offsets[k].bytes + terms[k].bytes + links[k].bytes;
+    size_t total = queue_f[0].bytes + queue_f[1].bytes + queue_rem[0].bytes + queue_rem[1].bytes + counts.bytes + offsets.bytes + index.bytes + scan_temp.bytes;
+    for (int k = 0; k < LEVELS_MAX; ++k) total += ray_of_slot[k].bytes + terms[k].bytes + links[k].bytes;
     return total;
 }
 
@@ -369,8 +383,8 @@ void level_arena_release(LevelArena &A) {
         b = ArenaBuffer();
     };
     for (int k = 0; k < 2; ++k) drop(A.queue_f[k]), drop(A.queue_rem[k]);
-    drop(A.counts), drop(A.index), drop(A.scan_temp);
-    for (int k = 0; k < LEVELS_MAX; ++k) drop(A.offsets[k]), drop(A.terms[k]), drop(A.links[k]);
+    drop(A.counts), drop(A.offsets), drop(A.index), drop(A.scan_temp);
+    for (int k = 0; k < LEVELS_MAX; ++k) drop(A.ray_of_slot[k]), drop(A.terms[k]), drop(A.links[k]);
     if (A.host_totals) (void)hipHostFree(A.host_totals);
     A.host_totals = nullptr;
     A.levels = 0;
