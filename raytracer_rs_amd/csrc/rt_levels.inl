@@ -23,17 +23,22 @@
 // deepest first, adds to every ray the sums of its two children -- reflection, then refraction: the order of
 // world.rs:107-110.  A pixel's colour is therefore a function of its own ray tree alone: it does not depend on the
 // launch, the rows rendered with it, or the order in which waves run.
-// Waves per SIMD: six (80 VGPRs) for the general build, whose node tables are large and whose record fetches miss the
-// scalar cache -- the generated scene at 8K 62.7 ms against 63.8 at five and 68.9 at four; five for the build without
-// cone directions (chapter_14 with levels forced: 4.5 ms at five, 4.8 at four, 5.0 at six).
+// Five waves per SIMD (96 VGPRs, ten to twenty of the traversal's values spilled).  The generated scene at 8K: 55.9 ms
+// at five, 57.2 at six, 67.4 at seven (and, before rays were binned by octant, 63.8 / 62.7 at five / six, 68.9 at four).
 #ifndef RT_LEVEL_WAVES
-#define RT_LEVEL_WAVES(NEST) ((NEST) == 2 ? 5 : 6)
+#define RT_LEVEL_WAVES 5
 #endif
+// Direction bins per kind: the octant (8).  Octant x longest axis (24) was measured too: 64.2 ms against 57.2 at 8K --
+// finer bins take a wave's 64 rays from a larger part of the screen.
 
 namespace {
 
 constexpr unsigned NO_CHILD = 0xffu;
-constexpr unsigned LEVEL_BINS = 16;  // kind (reflection, refraction) x octant of the direction (bit a set: towards -a, as DeviceScene::oct_tables)
+#ifndef RT_LEVEL_DIR_BINS
+#define RT_LEVEL_DIR_BINS 8
+#endif
+constexpr unsigned DIR_BINS = RT_LEVEL_DIR_BINS;  // 8: octant of the direction (bit a set: towards -a, as DeviceScene::oct_tables); 24: x its longest axis
+constexpr unsigned LEVEL_BINS = 2 * DIR_BINS;     // kind (reflection, refraction) x direction bin
 
 struct LevelIO {
     // the rays of this level (unused at level 0)
@@ -62,7 +67,7 @@ __device__ __forceinline__ bool level0_tile(unsigned wave, unsigned blocks_x, un
 }
 
 template <int NEST, bool TIES, bool FIRST>
-__global__ __launch_bounds__(64, RT_LEVEL_WAVES(NEST)) void level_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth, LevelIO io) {
+__global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth, LevelIO io) {
     const unsigned lane = threadIdx.x & 63;
     const unsigned wave = blockIdx.x;
     SceneK S = scene_k<NEST, false>(scene, max_depth);
@@ -104,13 +109,17 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES(NEST)) void level_kernel(DeviceS
     // The wave's children of one kind, packed into its 64 slots for that kind, octant after octant; returns the lane's k
     // (NO_CHILD if none).
     auto append = [&](bool want, unsigned kind, V3 o, V3 d, double pw, int prem) -> unsigned {
-        const unsigned oct = (d.x < 0.0 ? 1u : 0u) | (d.y < 0.0 ? 2u : 0u) | (d.z < 0.0 ? 4u : 0u);
+        unsigned oct = (d.x < 0.0 ? 1u : 0u) | (d.y < 0.0 ? 2u : 0u) | (d.z < 0.0 ? 4u : 0u);
+        if constexpr (DIR_BINS == 24) {
+            const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
+            oct = oct * 3u + (ax >= ay && ax >= az ? 0u : ay >= az ? 1u : 2u);
+        }
         unsigned k = 0, before = 0;
 #pragma unroll
-        for (unsigned b = 0; b < 8; ++b) {
+        for (unsigned b = 0; b < DIR_BINS; ++b) {
             const unsigned long long m = __ballot(want && oct == b);
             const unsigned n = (unsigned)__popcll(m);
-            if (lane == b) io.out_counts[(kind * 8u + b) * (io.waves + 1u) + wave] = n;
+            if (lane == b) io.out_counts[(kind * DIR_BINS + b) * (io.waves + 1u) + wave] = n;
             if (oct == b) k = before + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             before += n;
         }
@@ -220,8 +229,8 @@ __global__ __launch_bounds__(64) void level_index_kernel(const uint32_t *__restr
                                                          uint32_t *__restrict__ slot_of_ray, uint32_t *__restrict__ ray_of_slot) {
     const unsigned kind = blockIdx.x >= waves ? 1u : 0u, p = blockIdx.x - kind * waves, k = threadIdx.x;
     unsigned before = 0;
-    for (unsigned b = 0; b < 8; ++b) {
-        const size_t at = (size_t)(kind * 8u + b) * (waves + 1u) + p;
+    for (unsigned b = 0; b < DIR_BINS; ++b) {
+        const size_t at = (size_t)(kind * DIR_BINS + b) * (waves + 1u) + p;
         const unsigned n = counts[at];
         if (k >= before && k < before + n) {
             const size_t slot = (size_t)kind * 64 * waves + (size_t)p * 64 + k;
