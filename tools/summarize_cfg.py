@@ -30,6 +30,8 @@ def main() -> None:
     ap.add_argument("--flops", type=float, default=0.0, help="default: the figure perf.py printed in the kernel-trace run")
     ap.add_argument("--resource-usage", default=None)
     ap.add_argument("--note", default="")
+    ap.add_argument("--frames", type=int, default=0, help="the needle's kernel is launched several times per frame (the level renderer): "
+                    "figures are summed over all its launches and divided by this number of frames (perf.py's --reps of the pass)")
     ap.add_argument("--config", default=None, help="also record HBM bytes and executed flops under this name in profiles/pmc_traffic.json")
     a = ap.parse_args()
     src = os.path.join(ROOT, "gpurun_out", f"prof_{a.tag}")
@@ -56,9 +58,14 @@ def main() -> None:
             name = row["Name"]
             lines.append(f"| `{short_name(name)}` | {row['Calls']} | {float(row['AverageNs']) / 1e6:.4f} | {float(row['MinNs']) / 1e6:.4f} | "
                          f"{float(row['MaxNs']) / 1e6:.4f} | {float(row['Percentage']):.2f} |")
-            if a.needle in name and avg_ms is None:
+            if a.needle in name and avg_ms is None and not a.frames:
                 avg_ms = float(row["AverageNs"]) / 1e6
+            if a.needle in name and a.frames:
+                avg_ms = (avg_ms or 0.0) + float(row["TotalDurationNs"]) / 1e6 / a.frames
     lines.append("")
+    if a.frames:
+        lines += [f"`{a.needle}` is launched once per level of the ray trees: summed over its launches, {avg_ms:.4f} ms per frame "
+                  f"(the kernel-trace pass rendered {a.frames} frames; every figure below is per frame likewise).", ""]
     kernel_full = None
     with open(os.path.join(src, "trace_kernel_trace.csv")) as f:
         for row in csv.DictReader(f):
@@ -88,8 +95,14 @@ def main() -> None:
             for d in per_dispatch.values():
                 for k, v in d.items():
                     counters[k].append(v)
-    mean = {k: sum(v) / len(v) for k, v in counters.items()}
-    lines += [f"## Counters, mean per launch of `{a.needle}` (`--pmc`, one pass per group)", "", "| counter | value |", "|---|---|"]
+    if a.frames:
+        # counter passes run fewer frames than the kernel-trace pass: launches per frame x frames of that pass
+        with open(os.path.join(src, "trace_kernel_trace.csv")) as f:
+            per_frame = sum(1 for r in csv.DictReader(f) if a.needle in r["Kernel_Name"]) / a.frames
+        mean = {k: sum(v) / (len(v) / per_frame) for k, v in counters.items()}
+    else:
+        mean = {k: sum(v) / len(v) for k, v in counters.items()}
+    lines += [f"## Counters, mean per {'frame' if a.frames else 'launch'} of `{a.needle}` (`--pmc`, one pass per group)", "", "| counter | value |", "|---|---|"]
     for k in sorted(mean):
         lines.append(f"| {k} | {mean[k]:.6g} |")
     lines.append("")
