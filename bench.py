@@ -111,7 +111,7 @@ def measured_fp64_peak() -> dict:
 
 def device_source_hash() -> str:
     h = hashlib.sha256()
-    for name in ("rt_device.hip", "rt_device_types.h", "rt_flatten.cpp"):
+    for name in ("rt_device.hip", "rt_levels.inl", "rt_device_types.h", "rt_flatten.cpp"):
         with open(os.path.join(ROOT, "raytracer_rs_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -171,7 +171,8 @@ def time_config(scene, cam, stream, reps: int, quantized: bool, config: str = No
            "kernel_ms": round(kernel_ms, 4), "tile_ordering_ms": round(ordering_ms, 4),
            "mrays_per_s": round(counts["rays"] / wall_ms / 1e3, 1), "algorithmic_flops": flops,
            "reference_work_tflops": round(ref_tf, 3),
-           "frac": round(ref_tf / FP64_VECTOR_PEAK_TFLOPS, 4), "kernel": kernel_name(scene)}
+           "frac": round(ref_tf / FP64_VECTOR_PEAK_TFLOPS, 4), "kernel": kernel_name(scene),
+           "scene_device_mb": round(scene.info().device_bytes / 1e6, 1)}  # tables, and the ray queues of worlds rendered level by level
     if peak:
         out["frac_reference_work_of_measured_unfused"] = round(ref_tf / peak["unfused"], 4)
     if config:

@@ -313,7 +313,6 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
     const unsigned tiles_x = (camera.hsize + 7) / 8, tiles_y = (rows.n_rows + 7) / 8;
     const unsigned blocks_x = (tiles_x + 7) / 8, blocks_y = (tiles_y + 7) / 8;
     if ((unsigned long long)blocks_x * blocks_y * 64 > 0x00ffffffull) return hipErrorInvalidValue;  // 2^24 waves: 2^31 queue slots
-    if ((unsigned long long)(blocks_x * blocks_y * 64 + 1) * LEVEL_BINS > 0x7fffffffull) return hipErrorInvalidValue;  // (the scan counts in int)
     if (!A.host_totals) RT_TRY(hipHostMalloc((void **)&A.host_totals, 2 * sizeof(uint32_t), 0));
     const size_t lds = lds_bytes<NEST, false>(64);
     unsigned waves = blocks_x * blocks_y * 64, n_rays = waves * 64, levels = 0;
@@ -324,6 +323,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         RT_TRY(reserve(A.terms[level], (size_t)waves * 64 * 3 * sizeof(double)));
         RT_TRY(reserve(A.links[level], (size_t)waves * 64 * 2));
         const size_t table = ((size_t)waves + 1) * LEVEL_BINS;  // per bin: one count per wave and a last entry that stays zero
+        if (table > 0x7fffffffull) return hipErrorInvalidValue;  // (the scan counts its items in an int)
         RT_TRY(reserve(A.counts, table * sizeof(uint32_t)));
         if (!last) {
             RT_TRY(reserve(A.queue_f[out], (size_t)waves * 128 * 7 * sizeof(double)));

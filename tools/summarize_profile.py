@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def device_source_hash() -> str:
     """The same hash bench.py computes: identifies the kernel sources a PMC figure belongs to."""
     h = hashlib.sha256()
-    for name in ("rt_device.hip", "rt_device_types.h", "rt_flatten.cpp"):
+    for name in ("rt_device.hip", "rt_levels.inl", "rt_device_types.h", "rt_flatten.cpp"):
         with open(os.path.join(ROOT, "raytracer_rs_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
