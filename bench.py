@@ -299,11 +299,15 @@ def run_multi_parent(args) -> None:
     import subprocess
 
     base = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + ["--multi-child"]
-    limit = float(os.environ.get("RT_BENCH_CHILD_TIMEOUT", "420"))
+    limit_all = float(os.environ.get("RT_BENCH_CHILD_TIMEOUT", "420"))
     attempts = [dict()] if os.environ.get("RT_MULTI_GATHER") else [dict(), dict(RT_MULTI_GATHER="copy")]
     note = None
     for k, extra in enumerate(attempts):
         env = dict(os.environ, **extra)
+        if k == 0 and len(attempts) > 1:
+            limit = min(limit_all, 300.0)  # (the repeat with peer copies must still fit if RCCL stalls)
+        else:
+            limit = limit_all
         if note:
             env["RT_BENCH_NOTE"] = note
         try:
@@ -336,12 +340,49 @@ def run_multi_child(args) -> None:
     world = sf.build_world()
     W, H = cam.hsize, cam.vsize
     u8 = args.frame == "u8"
-    t_create = time.perf_counter()
-    multi = world.multi_scene(devices)
-    create_ms = (time.perf_counter() - t_create) * 1e3
     frame = torch.empty(W * H * 3, dtype=torch.uint8 if u8 else torch.float64, device=dev)
     band_rows = int(os.environ.get("RT_BENCH_BAND_ROWS", "0"))  # developer knobs: stripe height and number of units
     units = int(os.environ.get("RT_BENCH_UNITS", "0"))
+    # Two ways for the other GPUs' units to reach the first GPU exist (RCCL send/receive pairs, peer copies behind each
+    # kernel); which one is faster depends on the frame and the number of GPUs.  With more than one GPU and no choice made
+    # in the environment both are set up and tried on a few untimed frames, and the timed region runs the faster one.
+    calibration = {}
+    t_create = time.perf_counter()
+    # (RT_BENCH_CALIBRATE=1 runs the comparison on one GPU too, where both handles collect nothing: a rehearsal of this code)
+    if (len(set(devices)) > 1 or os.environ.get("RT_BENCH_CALIBRATE")) and not os.environ.get("RT_MULTI_GATHER"):
+        best = None
+        for mode in ("rccl", "copy"):
+            os.environ["RT_MULTI_GATHER"] = mode
+            try:
+                candidate = world.multi_scene(devices)
+            except rt.RtError as e:
+                calibration[mode] = f"not available: {e}"
+                continue
+            finally:
+                del os.environ["RT_MULTI_GATHER"]
+            for _ in range(10):
+                candidate.render_device(cam, frame.data_ptr(), band_rows=band_rows, quantized=u8, units=units)
+            for d in sorted(set(devices)):
+                torch.cuda.synchronize(d)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                candidate.render_device(cam, frame.data_ptr(), band_rows=band_rows, quantized=u8, units=units)
+            for d in sorted(set(devices)):
+                torch.cuda.synchronize(d)
+            ms = (time.perf_counter() - t0) / 20 * 1e3
+            calibration[mode] = round(ms, 4)
+            if best is None or ms < best[0]:
+                if best is not None:
+                    best[1].close()
+                best = (ms, candidate)
+            else:
+                candidate.close()
+        if best is None:
+            raise SystemExit("neither way of collecting the frame could be set up: " + json.dumps(calibration))
+        multi = best[1]
+    else:
+        multi = world.multi_scene(devices)
+    create_ms = (time.perf_counter() - t_create) * 1e3
 
     def sync_all():
         for d in sorted(set(devices)):
@@ -410,6 +451,7 @@ def run_multi_child(args) -> None:
                    "path": "single process, rt_multi_render_device",
                    "rays_per_frame": rays_frame, "rays_per_pixel": round(rays_frame / (W * H), 3)},
         "gather": info["gather"], "rccl_ranks": info["rccl_ranks"], "gather_note": info["note"],
+        "gather_calibration_ms": calibration or None,
         "units": info["n_units"], "stripe_rows": info["band_rows"], "units_taken": taken,
         "worker_render_ms": [round(v, 4) for v in worker_ms],
         "render_ms": round(sum(render_ms) / max(1, len(render_ms)), 4),

@@ -48,7 +48,7 @@ def _plain_env():
 def test_bench_drives_several_workers_without_a_launcher(gpu):
     """`python bench.py --gpus 2` started plainly: one process, rt_multi_render_device, two workers (here both on GPU 0 via
     RT_BENCH_DEVICES), the collected frame equal to the single-GPU frame (`--check`, exit status 3 otherwise)."""
-    env = dict(_plain_env(), RT_BENCH_DEVICES="0,0")
+    env = dict(_plain_env(), RT_BENCH_DEVICES="0,0", RT_BENCH_CALIBRATE="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--check",
            "--no-cpu-baseline", "--width", "1920", "--height", "1080"]
     done = subprocess.run(cmd, capture_output=True, text=True, timeout=170, env=env, cwd=ROOT)
@@ -61,6 +61,10 @@ def test_bench_drives_several_workers_without_a_launcher(gpu):
     assert sum(line["units_taken"]) == line["units"] >= 2 and len(line["units_taken"]) == 2
     assert line["value"] > 0 and line["config"]["rays_per_frame"] > 1920 * 1080 and line["gather_ms"] >= 0.0
     assert line["render_ms"] > 0.0 and len(line["worker_render_ms"]) == 2
+    # with several GPUs both ways of collecting the frame are tried on untimed frames and the faster one is timed;
+    # RT_BENCH_CALIBRATE=1 rehearses that on the one GPU there is (both handles then collect nothing)
+    cal = line["gather_calibration_ms"]
+    assert set(cal) == {"rccl", "copy"} and all(isinstance(v, float) and v > 0.0 for v in cal.values())
 
 
 def test_bench_refuses_more_gpus_than_there_are(gpu):
