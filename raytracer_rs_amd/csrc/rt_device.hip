@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>  // launch_render_levels scans its per-wave ray counts
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdlib>
 #include <mutex>

@@ -402,22 +402,55 @@ void level_arena_release(LevelArena &A) {
     A.levels = 0;
 }
 
+// Frames of more pixels than this are rendered in chunks of rows, one after the other through the same arena: the
+// queues of a frame grow with its pixels (about 0.5 KB per pixel for a scene whose ray trees are full), a pixel's
+// colour does not depend on what is rendered with it, and a chunk of this size still fills the GPU hundreds of times
+// over.  48 Mpixel: a 7680x4320 frame is one chunk.  RT_LEVELS_CHUNK_PIXELS in the environment overrides (tests).
+constexpr unsigned long long LEVELS_CHUNK_PIXELS = 48ull << 20;
+
 hipError_t launch_render_levels(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows_in, int max_depth, double *rgb,
                                 LevelArena &arena, hipStream_t stream, hipEvent_t *marks) {
     if (rows_in.n_rows == 0 || camera.hsize == 0 || rows_in.band_rows == 0) return hipSuccess;
     if (scene.max_nesting == 0) return hipErrorInvalidValue;
-    RowMap rows = rows_in;
-    rows.n_tiles = ((camera.hsize + 7) / 8) * ((rows.n_rows + 7) / 8);
-    rows.tile_list = nullptr;
     if (marks) {
         hipError_t e = hipEventRecord(marks[0], stream);
         if (e == hipSuccess) e = hipEventRecord(marks[1], stream);
         if (e != hipSuccess) return e;
     }
-    hipError_t e;
-    if (scene.any_order != 0 && scene.cone_nodes == 0) e = render_levels<2, true>(scene, camera, rows, max_depth, rgb, arena, stream);
-    else if (scene.any_order != 0) e = render_levels<1, true>(scene, camera, rows, max_depth, rgb, arena, stream);
-    else e = render_levels<1, false>(scene, camera, rows, max_depth, rgb, arena, stream);
+    unsigned long long limit = LEVELS_CHUNK_PIXELS;
+    if (const char *env = getenv("RT_LEVELS_CHUNK_PIXELS")) {
+        const unsigned long long v = strtoull(env, nullptr, 10);
+        if (v) limit = v;
+    }
+    // chunks of packed rows [r0, r1): whole bands when the rows are bands of a frame, multiples of 64 rows otherwise
+    const bool banded = rows_in.band_pitch != 0;
+    const unsigned unit = banded ? rows_in.band_rows : 64u;
+    unsigned long long chunk = limit / camera.hsize / unit * unit;
+    if (chunk < unit) chunk = unit;
+    hipError_t e = hipSuccess;
+    for (unsigned long long r0 = 0; r0 < rows_in.n_rows && e == hipSuccess; r0 += chunk) {
+        const unsigned r1 = (unsigned)std::min<unsigned long long>(rows_in.n_rows, r0 + chunk);
+        RowMap rows = rows_in;
+        rows.n_rows = r1 - (unsigned)r0;
+        if (banded) {
+            rows.row_begin = rows_in.row_begin + (unsigned)(r0 / rows_in.band_rows) * rows_in.band_pitch;
+        } else {
+            rows.row_begin = rows_in.row_begin + (unsigned)r0;
+            rows.row_end = std::min(rows_in.row_end, rows_in.row_begin + r1);
+            rows.band_rows = rows.n_rows;
+        }
+        double *out = rgb;
+        if (!rows.in_place) {  // packed output: the chunk's rows follow the rows before them
+            const size_t values = (size_t)r0 * camera.hsize * 3;
+            if (rows.quantized) rows.quantized += values;
+            else out += values;
+        }
+        rows.n_tiles = ((camera.hsize + 7) / 8) * ((rows.n_rows + 7) / 8);
+        rows.tile_list = nullptr;
+        if (scene.any_order != 0 && scene.cone_nodes == 0) e = render_levels<2, true>(scene, camera, rows, max_depth, out, arena, stream);
+        else if (scene.any_order != 0) e = render_levels<1, true>(scene, camera, rows, max_depth, out, arena, stream);
+        else e = render_levels<1, false>(scene, camera, rows, max_depth, out, arena, stream);
+    }
     if (e == hipSuccess && marks) e = hipEventRecord(marks[2], stream);
     return e;
 }

@@ -111,6 +111,43 @@ def test_every_way_to_cut_a_frame_gives_the_same_bits(gpu, rt, orc, levels):
         hip.hipFree(buf)
 
 
+def test_large_frames_are_rendered_in_chunks_of_rows(gpu, rt, orc, levels, monkeypatch):
+    """Beyond a number of pixels (48 Mpixel; RT_LEVELS_CHUNK_PIXELS overrides, read per call) a frame goes through the
+    queues in chunks of rows -- whole bands when the rows are bands -- and nothing about the result may change: packed
+    rows, bands, rows in place, 8-bit values."""
+    hip = _hip()
+    w, h = 403, 277
+    cam, world, _, _ = load_both(rt, orc, "chapter_14", w, h)
+    s = world.scene()
+    full, _ = s.render(cam)
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), full.nbytes + 64) == 0
+    try:
+        for limit in (w * 64, w * 100, w * 16):  # chunks of 64 rows, 64 rows (rounded down), one band of 16
+            monkeypatch.setenv("RT_LEVELS_CHUNK_PIXELS", str(limit))
+            assert hip.hipMemset(buf, 0xA5, full.nbytes + 64) == 0
+            s.render_device(cam, buf.value)
+            got = _fetch(hip, buf, full.nbytes + 64, np.uint8)
+            assert np.array_equal(got[:full.nbytes].view(np.float64).reshape(full.shape), full), limit
+            assert (got[full.nbytes:] == 0xA5).all(), "wrote past the frame"
+            s.render_device(cam, buf.value, rows=(3, 250))
+            assert np.array_equal(_fetch(hip, buf, (247, w, 3), np.float64), full[3:250]), limit
+            s.render_device(cam, buf.value, quantized=True)
+            assert np.array_equal(_fetch(hip, buf, (h, w, 3), np.uint8), orc.quantize(full)), limit
+            # stripes 2, 5, 8, ... packed one after the other, then the same stripes at their own rows
+            s.render_device_bands(cam, buf.value, 16, 2, 3)
+            want = np.concatenate([full[16 * k:16 * k + 16] for k in range(2, (h + 15) // 16, 3)])
+            assert np.array_equal(_fetch(hip, buf, want.shape, np.float64), want), limit
+            assert hip.hipMemset(buf, 0, full.nbytes) == 0
+            s.render_device_bands(cam, buf.value, 16, 2, 3, in_place=True)
+            got = _fetch(hip, buf, full.shape, np.float64)
+            for k in range((h + 15) // 16):
+                rows = slice(16 * k, min(h, 16 * k + 16))
+                assert np.array_equal(got[rows], full[rows] if k % 3 == 2 else np.zeros_like(full[rows])), (limit, k)
+    finally:
+        hip.hipFree(buf)
+
+
 def test_several_workers_level_by_level(gpu, rt, orc, levels):
     """rt_multi_* over a world rendered level by level: workers, units and stripes as for any world; the frame is the
     single-handle frame bit for bit (f64 in device memory, 8-bit, host), the counters are the counting kernel's."""
