@@ -1094,6 +1094,93 @@ __device__ __forceinline__ void ray_for_pixel(const RtCameraDev &cam, unsigned p
 // next ray from the stack.  All lanes of a wave are thus always in the same phase: the two traversals never mix
 // scattered radiance rays with the coherent shadow rays, and the shading code runs once per round.  A lane whose
 // ray missed simply sits out the shadow traversal.
+// What a hit contributes and what it spawns: Intersection::prepare_computations (rendering/intersections.rs:45-63),
+// Material::lighting for both outcomes of the shadow test (materials.rs:122-172), the reflection and refraction rays
+// of World::reflected_color / refracted_color with their path weights and Schlick's blend (world.rs:105-108, 155-198,
+// intersections.rs:123-136), and the shadow ray of World::is_shadowed (world.rs:128-141).  `w` is the path weight of
+// the ray that hit, `remaining` its recursion budget.
+struct HitShade {
+    V3 lit, shadowed;          // surface colour if the light reaches the point / if it does not (not yet weighted)
+    int flags;                 // (counting kernel) bit 0: the lit colour has a diffuse term, bit 1: a specular one
+    bool reflect, refract;     // which children the hit spawns
+    bool from_inside;
+    V3 over, under;            // over_point, under_point (intersections.rs:60-63): where the children start
+    V3 normal;                 // at the hit, turned towards the eye: the reflection's direction is reflect(rd, normal) (intersections.rs:62)
+    V3 refract_dir;
+    double w_reflect, w_refract;
+    V3 shadow_dir;             // from `over` towards the light, normalised
+    double light_distance;
+};
+template <bool DIAGONAL, bool STATS>
+__device__ __forceinline__ void shade_hit(const RtLight &light, V3 light_pos, const RtSurface *s, V3 ro, V3 rd, double t, double w, int remaining,
+                                          HitShade &h, Ctr<STATS> &ctr) {
+    V3 point = ro + rd * t;
+    V3 object_point;
+    V3 normal = normal_at<DIAGONAL>(s, point, object_point);
+    V3 eye = -rd;
+    h.from_inside = dot(normal, eye) < 0.0;
+    if (h.from_inside) normal = -normal;
+    h.over = point + normal * EPS;
+    ctr.add(C_SHADES);
+    h.flags = 0;
+    lighting<STATS>(s, light, point, object_point, eye, normal, h.shadowed, h.lit, h.flags, ctr);
+
+    const double reflectivity = s->reflectivity;
+    const double transparency = s->transparency;
+    h.reflect = remaining != 0 && reflectivity != 0.0;   // world.rs:156-162
+    h.refract = remaining != 0 && transparency != 0.0;   // world.rs:175-181
+    double cos_i = dot(eye, normal);
+    // n1/n2 as Intersection::prepare_computations leaves them when handed the one-element list [self]
+    // (intersections.rs:41-43,66-103): n1 = 1.0, n2 = the hit object's refractive index; a non-finite t
+    // fails float_equal(t, t) and leaves both at 1.0.
+    const double n1 = 1.0;
+    const double n2 = (fabs(t - t) < EPS) ? s->refractive_index : 1.0;
+    h.refract_dir = mk(0.0, 0.0, 0.0);
+    if (h.refract) {  // world.rs:183-194
+        ctr.add(C_REFRACT_SETUPS);
+        double n_ratio = n1 / n2;
+        double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+        if (sin2_t > 1.0) {
+            h.refract = false;
+        } else {
+            double cos_t = sqrt(1.0 - sin2_t);
+            h.refract_dir = normal * (n_ratio * cos_i - cos_t) - eye * n_ratio;
+        }
+    }
+    h.w_reflect = w * reflectivity;
+    h.w_refract = w * transparency;
+    if (reflectivity > 0.0 && transparency > 0.0) {  // world.rs:105-108, intersections.rs:123-136
+        ctr.add(C_SCHLICK);
+        double c = cos_i;
+        double reflectance;
+        bool total = false;
+        if (n1 > n2) {
+            double n = n1 / n2;
+            double sin2_t = (n * n) * (1.0 - c * c);
+            if (sin2_t > 1.0) total = true;
+            c = sqrt(1.0 - sin2_t);
+        }
+        if (total) {
+            reflectance = 1.0;
+        } else {
+            double q = (n1 - n2) / (n1 + n2);
+            double r0 = q * q;
+            double m = 1.0 - c;
+            double m2 = m * m;
+            double m5 = m * (m2 * m2);  // powi(5)
+            reflectance = r0 + (1.0 - r0) * m5;
+        }
+        h.w_reflect = h.w_reflect * reflectance;
+        h.w_refract = h.w_refract * (1.0 - reflectance);
+    }
+    h.normal = normal;
+    h.under = point - normal * EPS;
+    V3 v = light_pos - h.over;  // World::is_shadowed (rendering/world.rs:128-141)
+    h.light_distance = magnitude(v);
+    h.shadow_dir = div_by_magnitude(v, h.light_distance);
+    ctr.add(C_SHADOW);
+}
+
 __device__ __forceinline__ double readlane_double(double v, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
@@ -1184,74 +1271,15 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
         double h_dist = 0.0;
         int h_flags = 0;
         if (shade) {
-            // Intersection::prepare_computations (rendering/intersections.rs:45-63)
-            const RtSurface *s = S.surfaces + best.leaf;
-            V3 point = ro + rd * best.t;
-            V3 object_point;
-            V3 normal = normal_at<NEST == 0>(s, point, object_point);
-            V3 eye = -rd;
-            const bool from_inside = dot(normal, eye) < 0.0;
-            if (from_inside) normal = -normal;
-            V3 over = point + normal * EPS;
-            ctr.add(C_SHADES);
-
-            V3 shadowed, lit;
-            lighting<STATS>(s, S.light, point, object_point, eye, normal, shadowed, lit, h_flags, ctr);
+            HitShade h;
+            shade_hit<NEST == 0, STATS>(S.light, light_pos, S.surfaces + best.leaf, ro, rd, best.t, w, remaining, h, ctr);
+            h_flags = h.flags;
             if constexpr (SHARE) {  // the two candidate terms; the sum is formed in the owner's lane, below
-                acc_lit = lit * w;
-                term = shadowed * w;
+                acc_lit = h.lit * w;
+                term = h.shadowed * w;
             } else {
-                acc_lit = acc + lit * w;
-                acc = acc + shadowed * w;
-            }
-
-            const double reflectivity = s->reflectivity;
-            const double transparency = s->transparency;
-            bool do_reflect = remaining != 0 && reflectivity != 0.0;   // world.rs:156-162
-            bool do_refract = remaining != 0 && transparency != 0.0;   // world.rs:175-181
-            double cos_i = dot(eye, normal);
-            // n1/n2 as Intersection::prepare_computations leaves them when handed the one-element list [self]
-            // (intersections.rs:41-43,66-103): n1 = 1.0, n2 = the hit object's refractive index; a non-finite t
-            // fails float_equal(t, t) and leaves both at 1.0.
-            const double n1 = 1.0;
-            const double n2 = (fabs(best.t - best.t) < EPS) ? s->refractive_index : 1.0;
-            V3 refr_dir = mk(0.0, 0.0, 0.0);
-            if (do_refract) {  // world.rs:183-194
-                ctr.add(C_REFRACT_SETUPS);
-                double n_ratio = n1 / n2;
-                double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
-                if (sin2_t > 1.0) {
-                    do_refract = false;
-                } else {
-                    double cos_t = sqrt(1.0 - sin2_t);
-                    refr_dir = normal * (n_ratio * cos_i - cos_t) - eye * n_ratio;
-                }
-            }
-            double w_reflect = w * reflectivity;
-            double w_refract = w * transparency;
-            if (reflectivity > 0.0 && transparency > 0.0) {  // world.rs:105-108, intersections.rs:123-136
-                ctr.add(C_SCHLICK);
-                double c = cos_i;
-                double reflectance;
-                bool total = false;
-                if (n1 > n2) {
-                    double n = n1 / n2;
-                    double sin2_t = (n * n) * (1.0 - c * c);
-                    if (sin2_t > 1.0) total = true;
-                    c = sqrt(1.0 - sin2_t);
-                }
-                if (total) {
-                    reflectance = 1.0;
-                } else {
-                    double q = (n1 - n2) / (n1 + n2);
-                    double r0 = q * q;
-                    double m = 1.0 - c;
-                    double m2 = m * m;
-                    double m5 = m * (m2 * m2);  // powi(5)
-                    reflectance = r0 + (1.0 - r0) * m5;
-                }
-                w_reflect = w_reflect * reflectance;
-                w_refract = w_refract * (1.0 - reflectance);
+                acc_lit = acc + h.lit * w;
+                acc = acc + h.shadowed * w;
             }
             const int child_remaining = remaining - 1;
             // The child pushed last is walked first.  For a hit from outside that is the reflection; for a hit from
@@ -1260,26 +1288,22 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
             // keeps the stack of pending rays shallow: on the 4K chapter_11 frame the bytes that pending rays below
             // the LDS levels write to scratch memory fall from 0.61 GB to 0.21 GB per frame, and the frame is 1 %
             // faster.  The order in which a pixel's terms are summed changes with it, the terms do not.
-            const bool reflect_last = do_reflect && !from_inside;
-            if (do_reflect && !reflect_last) {  // over_point, reflect_vector (intersections.rs:60-62)
+            const bool reflect_last = h.reflect && !h.from_inside;
+            if (h.reflect && !reflect_last) {
                 ctr.add(C_REFLECT);
-                push(over, reflect(rd, normal), w_reflect, child_remaining);
+                push(h.over, reflect(rd, h.normal), h.w_reflect, child_remaining);
             }
-            if (do_refract) {  // under_point, direction (intersections.rs:63, world.rs:194)
+            if (h.refract) {
                 ctr.add(C_REFRACT);
-                push(point - normal * EPS, refr_dir, w_refract, child_remaining);
+                push(h.under, h.refract_dir, h.w_refract, child_remaining);
             }
             if (reflect_last) {
                 ctr.add(C_REFLECT);
-                push(over, reflect(rd, normal), w_reflect, child_remaining);
+                push(h.over, reflect(rd, h.normal), h.w_reflect, child_remaining);
             }
-
-            // World::is_shadowed (rendering/world.rs:128-141)
-            V3 v = light_pos - over;
-            h_dist = magnitude(v);
-            sro = over;
-            srd = div_by_magnitude(v, h_dist);
-            ctr.add(C_SHADOW);
+            h_dist = h.light_distance;
+            sro = h.over;
+            srd = h.shadow_dir;
         }
         RT_TIC(tm2);
         if (__ballot(shade) != 0ull) {

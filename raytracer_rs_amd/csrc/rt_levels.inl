@@ -137,81 +137,19 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
     const Closest<TIES> best = trace<NEST, false, TIES>(S, ro, rd, have, (double)INFINITY, ctr);
     const bool shade = have && best.leaf >= 0 && S.light.has_light;  // else black: world.rs:124, world.rs:86-89
     V3 term_lit = mk(0.0, 0.0, 0.0), term = mk(0.0, 0.0, 0.0);
-    V3 sro = ro, srd = rd;
-    double h_dist = 0.0;
-    int h_flags = 0;
-    bool do_reflect = false, do_refract = false;
-    V3 refl_o = ro, refl_d = rd, refr_o = ro, refr_d = rd;
-    double w_reflect = 0.0, w_refract = 0.0;
+    HitShade h;
+    h.reflect = h.refract = false;
+    h.over = h.under = ro, h.normal = h.refract_dir = h.shadow_dir = rd;
+    h.w_reflect = h.w_refract = h.light_distance = 0.0;
     if (shade) {
-        // Intersection::prepare_computations (rendering/intersections.rs:45-63), Material::lighting for both outcomes
-        // of the shadow test, the children's rays and weights: the arithmetic of radiance(), statement for statement.
-        const RtSurface *s = S.surfaces + best.leaf;
-        V3 point = ro + rd * best.t;
-        V3 object_point;
-        V3 normal = normal_at<false>(s, point, object_point);
-        V3 eye = -rd;
-        const bool from_inside = dot(normal, eye) < 0.0;
-        if (from_inside) normal = -normal;
-        V3 over = point + normal * EPS;
-        V3 shadowed, lit;
-        lighting<false>(s, S.light, point, object_point, eye, normal, shadowed, lit, h_flags, ctr);
-        term_lit = lit * w;
-        term = shadowed * w;
-        const double reflectivity = s->reflectivity;
-        const double transparency = s->transparency;
-        do_reflect = remaining != 0 && reflectivity != 0.0;   // world.rs:156-162
-        do_refract = remaining != 0 && transparency != 0.0;   // world.rs:175-181
-        double cos_i = dot(eye, normal);
-        const double n1 = 1.0;  // (intersections.rs:41-43,66-103 on the one-element list: see radiance())
-        const double n2 = (fabs(best.t - best.t) < EPS) ? s->refractive_index : 1.0;
-        if (do_refract) {  // world.rs:183-194
-            double n_ratio = n1 / n2;
-            double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
-            if (sin2_t > 1.0) {
-                do_refract = false;
-            } else {
-                double cos_t = sqrt(1.0 - sin2_t);
-                refr_d = normal * (n_ratio * cos_i - cos_t) - eye * n_ratio;
-            }
-        }
-        w_reflect = w * reflectivity;
-        w_refract = w * transparency;
-        if (reflectivity > 0.0 && transparency > 0.0) {  // world.rs:105-108, intersections.rs:123-136
-            double c = cos_i;
-            double reflectance;
-            bool total = false;
-            if (n1 > n2) {
-                double n = n1 / n2;
-                double sin2_t = (n * n) * (1.0 - c * c);
-                if (sin2_t > 1.0) total = true;
-                c = sqrt(1.0 - sin2_t);
-            }
-            if (total) {
-                reflectance = 1.0;
-            } else {
-                double q = (n1 - n2) / (n1 + n2);
-                double r0 = q * q;
-                double m = 1.0 - c;
-                double m2 = m * m;
-                double m5 = m * (m2 * m2);  // powi(5)
-                reflectance = r0 + (1.0 - r0) * m5;
-            }
-            w_reflect = w_reflect * reflectance;
-            w_refract = w_refract * (1.0 - reflectance);
-        }
-        refl_o = over;  // over_point, reflect_vector (intersections.rs:60-62)
-        refl_d = reflect(rd, normal);
-        refr_o = point - normal * EPS;  // under_point (intersections.rs:63)
-        V3 v = light_pos - over;  // World::is_shadowed (rendering/world.rs:128-141)
-        h_dist = magnitude(v);
-        sro = over;
-        srd = div_by_magnitude(v, h_dist);
+        shade_hit<false, false>(S.light, light_pos, S.surfaces + best.leaf, ro, rd, best.t, w, remaining, h, ctr);
+        term_lit = h.lit * w;
+        term = h.shadowed * w;
     }
-    const unsigned k_reflect = append(shade && do_reflect, 0u, refl_o, refl_d, w_reflect, remaining - 1);
-    const unsigned k_refract = append(shade && do_refract, 1u, refr_o, refr_d, w_refract, remaining - 1);
+    const unsigned k_reflect = append(shade && h.reflect, 0u, h.over, reflect(rd, h.normal), h.w_reflect, remaining - 1);
+    const unsigned k_refract = append(shade && h.refract, 1u, h.under, h.refract_dir, h.w_refract, remaining - 1);
     if (__ballot(shade) != 0ull) {
-        const bool in_shadow = occluded<NEST, false>(S, sro, srd, shade, h_dist, ctr);  // world.rs:145-148
+        const bool in_shadow = occluded<NEST, false>(S, h.over, h.shadow_dir, shade, h.light_distance, ctr);  // world.rs:145-148
         if (shade && !in_shadow) term = term_lit;
     }
     const size_t n = (size_t)io.waves * 64, i = (size_t)wave * 64 + lane;
