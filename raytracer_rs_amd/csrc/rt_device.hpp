@@ -47,7 +47,7 @@ struct ArenaBuffer {
 };
 constexpr int LEVELS_MAX = RT_MAX_DEPTH + 1;  // level 0 = the rays through the pixels, level k = their k-th generation of children
 struct LevelArena {
-    ArenaBuffer queue_f[2], queue_rem[2];  // the rays a level reads and the rays it writes (origin, direction, weight; remaining budget)
+    ArenaBuffer queue_f[2];                // the rays a level reads and the rays it writes: 64 bytes each (origin, direction, weight, remaining budget)
     ArenaBuffer counts, offsets;           // children per bin and wave of the level being rendered, and the same scanned
     ArenaBuffer index;                     // ray number in the next level -> its slot in the queue
     ArenaBuffer ray_of_slot[LEVELS_MAX];   // the other way round, per level (kept for the sums: where a ray's children are)

@@ -42,17 +42,14 @@ constexpr unsigned LEVEL_BINS = 2 * DIR_BINS;     // kind (reflection, refractio
 
 struct LevelIO {
     // the rays of this level (unused at level 0)
-    const double *in_f = nullptr;       // seven arrays of in_slots doubles: origin, direction, weight
-    const uint8_t *in_rem = nullptr;    // remaining recursion budget
-    size_t in_slots = 0;
+    const double *in_f = nullptr;       // eight doubles per slot, one 64-byte line: origin, direction, weight, remaining budget
     const uint32_t *in_index = nullptr; // ray number -> slot
     uint32_t n_rays = 0;
     // what it writes
     double *out_f = nullptr;            // 128 slots per wave: kind * 64 * waves + wave * 64 + k
-    uint8_t *out_rem = nullptr;
     uint32_t *out_counts = nullptr;     // [LEVEL_BINS][waves + 1]: children per bin (kind * 8 + octant) and wave
     uint32_t waves = 0;
-    double *terms = nullptr;            // three arrays of 64 * waves doubles
+    double *terms = nullptr;            // three doubles per ray
     uint8_t *links = nullptr;           // two arrays of 64 * waves bytes: k of the ray's reflection / refraction, or NO_CHILD
     uint32_t blocks_x = 0;              // level 0: blocks of 8x8 tiles per row of blocks
 };
@@ -90,19 +87,18 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
         have = i < io.n_rays;
         if (have) {
             const unsigned slot = io.in_index[i];
-            const double *f = io.in_f + slot;
-            const size_t c = io.in_slots;
-            ro = mk(f[0], f[c], f[2 * c]);
-            rd = mk(f[3 * c], f[4 * c], f[5 * c]);
-            w = f[6 * c];
-            remaining = io.in_rem[slot];
+            const double4 *f = reinterpret_cast<const double4 *>(io.in_f + (size_t)slot * 8);
+            const double4 a = f[0], b = f[1];
+            ro = mk(a.x, a.y, a.z);
+            rd = mk(a.w, b.x, b.y);
+            w = b.z;
+            remaining = __double2loint(b.w);
         }
     }
-    const size_t out_slots = (size_t)io.waves * 128;
     if (FIRST && __ballot(have) == 0ull) {  // a tile outside the frame (the launch is padded to whole blocks of tiles)
         const size_t n = (size_t)io.waves * 64, i = (size_t)wave * 64 + lane;
         if (lane < LEVEL_BINS) io.out_counts[lane * (io.waves + 1u) + wave] = 0u;
-        io.terms[i] = 0.0, io.terms[n + i] = 0.0, io.terms[2 * n + i] = 0.0;
+        io.terms[3 * i] = 0.0, io.terms[3 * i + 1] = 0.0, io.terms[3 * i + 2] = 0.0;
         io.links[i] = (uint8_t)NO_CHILD, io.links[n + i] = (uint8_t)NO_CHILD;
         return;
     }
@@ -125,11 +121,9 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
         }
         if (!want) return NO_CHILD;
         const size_t slot = (size_t)kind * 64 * io.waves + (size_t)wave * 64 + k;
-        double *f = io.out_f + slot;
-        f[0] = o.x, f[out_slots] = o.y, f[2 * out_slots] = o.z;
-        f[3 * out_slots] = d.x, f[4 * out_slots] = d.y, f[5 * out_slots] = d.z;
-        f[6 * out_slots] = pw;
-        io.out_rem[slot] = (uint8_t)prem;
+        double4 *f = reinterpret_cast<double4 *>(io.out_f + slot * 8);
+        f[0] = make_double4(o.x, o.y, o.z, d.x);
+        f[1] = make_double4(d.y, d.z, pw, __hiloint2double(0, prem));
         return k;
     };
 
@@ -153,22 +147,26 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
         if (shade && !in_shadow) term = term_lit;
     }
     const size_t n = (size_t)io.waves * 64, i = (size_t)wave * 64 + lane;
-    io.terms[i] = term.x;
-    io.terms[n + i] = term.y;
-    io.terms[2 * n + i] = term.z;
+    io.terms[3 * i] = term.x;
+    io.terms[3 * i + 1] = term.y;
+    io.terms[3 * i + 2] = term.z;
     io.links[i] = (uint8_t)k_reflect;
     io.links[n + i] = (uint8_t)k_refract;
 }
 
 // Numbers the children of one level: child k of kind `kind` of parent wave p lies in slot kind * 64 * waves + p * 64 + k;
 // its bin is the one whose run of p's block holds k, and its number in the next level is the scanned count of (bin, p)
-// plus its place in that run.  Writes both directions of the mapping.  One single-wave workgroup per (parent, kind), a
-// lane per slot: the counts are wave-uniform reads (scalar loads) and the writes to ray_of_slot contiguous.  2 ms of an
-// 8K frame of the generated scene; measured and slower: four such waves to a workgroup (the wave's number is no longer
-// known to be uniform: +1.5 ms), one thread per (parent, bin) writing its run serially (+3 ms).
-__global__ __launch_bounds__(64) void level_index_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets, uint32_t waves,
-                                                         uint32_t *__restrict__ slot_of_ray, uint32_t *__restrict__ ray_of_slot) {
-    const unsigned kind = blockIdx.x >= waves ? 1u : 0u, p = blockIdx.x - kind * waves, k = threadIdx.x;
+// plus its place in that run.  Writes both directions of the mapping.  One wave per (parent, kind), a lane per slot:
+// the counts are wave-uniform reads (scalar loads) and the writes to ray_of_slot contiguous; four waves to a
+// workgroup.  2 ms of an 8K frame of the generated scene.  (Measured and slower: the same without telling the compiler
+// that a wave's unit is uniform -- the counts then come through vector loads, +1.5 ms -- and one thread per (parent, bin)
+// writing its run serially, +3 ms.)
+__global__ __launch_bounds__(256) void level_index_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets, uint32_t waves,
+                                                          uint32_t *__restrict__ slot_of_ray, uint32_t *__restrict__ ray_of_slot) {
+    // (readfirstlane: the unit is the same for a wave's 64 lanes, and saying so keeps the counts in scalar loads)
+    const unsigned unit = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));  // (parent, kind)
+    if (unit >= 2u * waves) return;
+    const unsigned kind = unit >= waves ? 1u : 0u, p = unit - kind * waves, k = threadIdx.x & 63u;
     unsigned before = 0;
     for (unsigned b = 0; b < DIR_BINS; ++b) {
         const size_t at = (size_t)(kind * DIR_BINS + b) * (waves + 1u) + p;
@@ -186,25 +184,25 @@ __global__ __launch_bounds__(64) void level_index_kernel(const uint32_t *__restr
 // Children before parents: a ray's sum = its own term + the sum of its reflection + the sum of its refraction
 // (the order of world.rs:107-110).  `child` holds the finished sums of the next level.
 __global__ __launch_bounds__(256) void level_sum_kernel(double *__restrict__ terms, const uint8_t *__restrict__ links, const uint32_t *__restrict__ ray_of_slot,
-                                                        uint32_t waves, uint32_t n_rays, const double *__restrict__ child, size_t child_n) {
+                                                        uint32_t waves, uint32_t n_rays, const double *__restrict__ child) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rays) return;
     const size_t n = (size_t)waves * 64;
     const size_t block = (i >> 6) * 64;
     const unsigned k0 = links[i], k1 = links[n + i];
     if (k0 == NO_CHILD && k1 == NO_CHILD) return;
-    V3 sum = mk(terms[i], terms[n + i], terms[2 * n + i]);
+    V3 sum = mk(terms[3 * i], terms[3 * i + 1], terms[3 * i + 2]);
     if (k0 != NO_CHILD) {
-        const size_t j = ray_of_slot[block + k0];
-        sum = sum + mk(child[j], child[child_n + j], child[2 * child_n + j]);
+        const size_t j = 3 * (size_t)ray_of_slot[block + k0];
+        sum = sum + mk(child[j], child[j + 1], child[j + 2]);
     }
     if (k1 != NO_CHILD) {
-        const size_t j = ray_of_slot[n + block + k1];
-        sum = sum + mk(child[j], child[child_n + j], child[2 * child_n + j]);
+        const size_t j = 3 * (size_t)ray_of_slot[n + block + k1];
+        sum = sum + mk(child[j], child[j + 1], child[j + 2]);
     }
-    terms[i] = sum.x;
-    terms[n + i] = sum.y;
-    terms[2 * n + i] = sum.z;
+    terms[3 * i] = sum.x;
+    terms[3 * i + 1] = sum.y;
+    terms[3 * i + 2] = sum.z;
 }
 
 // The finished sums of level 0 are the pixels: Canvas::write_pixel per tile, as render_kernel does it.
@@ -219,8 +217,8 @@ __global__ __launch_bounds__(64) void level_store_kernel(RtCameraDev cam, RowMap
     const unsigned r = (tile / tiles_x) * 8 + (lane >> 3);
     const unsigned y = image_row(rows, r);
     const bool valid = x < cam.hsize && r < rows.n_rows && y < rows.row_end;
-    const size_t n = (size_t)waves * 64, i = (size_t)wave * 64 + lane;
-    const V3 acc = mk(terms[i], terms[n + i], terms[2 * n + i]);
+    const size_t i = (size_t)wave * 64 + lane;
+    const V3 acc = mk(terms[3 * i], terms[3 * i + 1], terms[3 * i + 2]);
     store_tile(cam, rows, tile, lane, valid, x, r, y, acc, staging, rgb);
 }
 
@@ -264,19 +262,15 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         if (table > 0x7fffffffull) return hipErrorInvalidValue;  // (the scan counts its items in an int)
         RT_TRY(reserve(A.counts, table * sizeof(uint32_t)));
         if (!last) {
-            RT_TRY(reserve(A.queue_f[out], (size_t)waves * 128 * 7 * sizeof(double)));
-            RT_TRY(reserve(A.queue_rem[out], (size_t)waves * 128));
+            RT_TRY(reserve(A.queue_f[out], (size_t)waves * 128 * 8 * sizeof(double)));
             RT_TRY(reserve(A.offsets, table * sizeof(uint32_t)));
             RT_TRY(reserve(A.ray_of_slot[level], (size_t)waves * 128 * sizeof(uint32_t)));
         }
         LevelIO io;
         io.in_f = (const double *)A.queue_f[in].p;
-        io.in_rem = (const uint8_t *)A.queue_rem[in].p;
-        io.in_slots = level == 0 ? 0 : (size_t)level_waves[level - 1] * 128;
         io.in_index = (const uint32_t *)A.index.p;
         io.n_rays = n_rays;
         io.out_f = (double *)A.queue_f[out].p;
-        io.out_rem = (uint8_t *)A.queue_rem[out].p;
         io.out_counts = (uint32_t *)A.counts.p;
         io.waves = waves;
         io.terms = (double *)A.terms[level].p;
@@ -303,7 +297,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         if (children == 0) break;
         if (children > 0x3fffffffull) return hipErrorOutOfMemory;
         RT_TRY(reserve(A.index, (size_t)children * sizeof(uint32_t)));
-        level_index_kernel<<<dim3(2 * waves), 64, 0, stream>>>(counts, offsets, waves, (uint32_t *)A.index.p, (uint32_t *)A.ray_of_slot[level].p);
+        level_index_kernel<<<dim3((2 * waves + 3) / 4), 256, 0, stream>>>(counts, offsets, waves, (uint32_t *)A.index.p, (uint32_t *)A.ray_of_slot[level].p);
         n_rays = (unsigned)children;
         waves = (n_rays + 63) / 64;
     }
@@ -311,7 +305,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         const unsigned w = level_waves[level];
         level_sum_kernel<<<dim3((A.level_rays[level] + 255) / 256), 256, 0, stream>>>((double *)A.terms[level].p, (const uint8_t *)A.links[level].p,
                                                                                      (const uint32_t *)A.ray_of_slot[level].p, w, A.level_rays[level],
-                                                                                     (const double *)A.terms[level + 1].p, (size_t)level_waves[level + 1] * 64);
+                                                                                     (const double *)A.terms[level + 1].p);
     }
     level_store_kernel<<<dim3(level_waves[0]), 64, 0, stream>>>(camera, rows, (const double *)A.terms[0].p, level_waves[0], blocks_x, rgb);
     A.levels = levels;
@@ -322,7 +316,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
 }  // namespace
 
 size_t LevelArena::device_bytes() const {
-    size_t total = queue_f[0].bytes + queue_f[1].bytes + queue_rem[0].bytes + queue_rem[1].bytes + counts.bytes + offsets.bytes + index.bytes + scan_temp.bytes;
+    size_t total = queue_f[0].bytes + queue_f[1].bytes + counts.bytes + offsets.bytes + index.bytes + scan_temp.bytes;
     for (int k = 0; k < LEVELS_MAX; ++k) total += ray_of_slot[k].bytes + terms[k].bytes + links[k].bytes;
     return total;
 }
@@ -332,7 +326,7 @@ void level_arena_release(LevelArena &A) {
         if (b.p) (void)hipFree(b.p);
         b = ArenaBuffer();
     };
-    for (int k = 0; k < 2; ++k) drop(A.queue_f[k]), drop(A.queue_rem[k]);
+    for (int k = 0; k < 2; ++k) drop(A.queue_f[k]);
     drop(A.counts), drop(A.offsets), drop(A.index), drop(A.scan_temp);
     for (int k = 0; k < LEVELS_MAX; ++k) drop(A.ray_of_slot[k]), drop(A.terms[k]), drop(A.links[k]);
     if (A.host_totals) (void)hipHostFree(A.host_totals);
