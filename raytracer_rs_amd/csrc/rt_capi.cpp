@@ -74,10 +74,13 @@ struct rt_scene_file {
 namespace {
 
 // Which worlds are rendered level by level: those with groups and at least RT_LEVELS_MIN_LEAVES leaves.  Measured on
-// MI355X: a generated hierarchy of 10 001 leaves renders 8 % (7680x4320) to 39 % (1920x1080) faster that way, the 344
-// leaves of chapter_14 1.5 % slower.  RT_RENDER_LEVELS=0 / 1 in the environment, read when a scene is created, forces
-// the choice for every world with groups (worlds without groups always take the single launch).
-constexpr uint32_t RT_LEVELS_MIN_LEAVES = 2048;
+// MI355X at 3840x2160: generated hierarchies of 901 / 2 501 / 10 001 leaves render 35 % / 18 % / 30 % faster that way
+// (the single launch waits for its longest waves there), chapter_14 (327 leaves) 1 % faster, and frames of a few
+// thousand pixels slower (six launches instead of one).  A level render blocks the caller once per level and needs
+// device memory that grows with the frame, so small worlds keep the single launch.  RT_RENDER_LEVELS=0 / 1 in the
+// environment, read when a scene is created, forces the choice for every world with groups (worlds without groups
+// always take the single launch).
+constexpr uint32_t RT_LEVELS_MIN_LEAVES = 512;
 bool render_by_levels(int max_nesting, uint32_t n_leaves) {
     if (max_nesting <= 0) return false;
     const char *e = getenv("RT_RENDER_LEVELS");

@@ -28,17 +28,20 @@
 #ifndef RT_LEVEL_WAVES
 #define RT_LEVEL_WAVES 5
 #endif
-// Direction bins per kind: the octant (8).  Octant x longest axis (24) was measured too: 64.2 ms against 57.2 at 8K --
-// finer bins take a wave's 64 rays from a larger part of the screen.
+// Direction bins per kind (DIRS): the octant of the direction (8) for hierarchies of LEVELS_OCTANT_MIN_LEAVES leaves and
+// more, none (1: kinds only, screen order) for smaller ones.  Measured at 3840x2160, single launch / levels with one
+// bin / with eight, ms: generated hierarchies of 101 leaves 1.69 / 1.41 / 1.58, 401 leaves 5.27 / 3.48 / 3.38, 901
+// leaves 7.9 / 5.35 / 5.05, 1 601 leaves 8.9 / 8.55 / 8.1, 2 501 leaves 16.7 / 15.3 / 13.7, 4 901 leaves 21.2 / 18.8 /
+// 16.1, 10 001 leaves 26.3 / 22.7 / 18.3; chapter_14 (327 leaves) 4.45 / 4.40 / 5.37 -- small mirror balls scatter its
+// rays, and only screen locality keeps a wave's rays together.  Octant x longest axis (24 bins) was measured too:
+// 64.2 ms against 57.2 on the 10 001-leaf scene at 8K: finer bins take a wave's 64 rays from a larger part of the screen.
+constexpr int LEVELS_OCTANT_MIN_LEAVES = 2048;
 
 namespace {
 
 constexpr unsigned NO_CHILD = 0xffu;
-#ifndef RT_LEVEL_DIR_BINS
-#define RT_LEVEL_DIR_BINS 8
-#endif
-constexpr unsigned DIR_BINS = RT_LEVEL_DIR_BINS;  // 8: octant of the direction (bit a set: towards -a, as DeviceScene::oct_tables); 24: x its longest axis
-constexpr unsigned LEVEL_BINS = 2 * DIR_BINS;     // kind (reflection, refraction) x direction bin
+// Bins of a level's children: kind (reflection, refraction) x direction bin (DIRS = 8: the octant, bit a set: towards -a,
+// as in DeviceScene::oct_tables; DIRS = 1: none).
 
 struct LevelIO {
     // the rays of this level (unused at level 0)
@@ -47,7 +50,7 @@ struct LevelIO {
     uint32_t n_rays = 0;
     // what it writes
     double *out_f = nullptr;            // 128 slots per wave: kind * 64 * waves + wave * 64 + k
-    uint32_t *out_counts = nullptr;     // [LEVEL_BINS][waves + 1]: children per bin (kind * 8 + octant) and wave
+    uint32_t *out_counts = nullptr;     // [2 * DIRS][waves + 1]: children per bin (kind * DIRS + direction bin) and wave
     uint32_t waves = 0;
     double *terms = nullptr;            // three doubles per ray
     uint8_t *links = nullptr;           // two arrays of 64 * waves bytes: k of the ray's reflection / refraction, or NO_CHILD
@@ -63,7 +66,7 @@ __device__ __forceinline__ bool level0_tile(unsigned wave, unsigned blocks_x, un
     return tx < tiles_x && ty < tiles_y;
 }
 
-template <int NEST, bool TIES, bool FIRST>
+template <int NEST, bool TIES, bool FIRST, unsigned DIRS>
 __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth, LevelIO io) {
     const unsigned lane = threadIdx.x & 63;
     const unsigned wave = blockIdx.x;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
     }
     if (FIRST && __ballot(have) == 0ull) {  // a tile outside the frame (the launch is padded to whole blocks of tiles)
         const size_t n = (size_t)io.waves * 64, i = (size_t)wave * 64 + lane;
-        if (lane < LEVEL_BINS) io.out_counts[lane * (io.waves + 1u) + wave] = 0u;
+        if (lane < 2u * DIRS) io.out_counts[lane * (io.waves + 1u) + wave] = 0u;
         io.terms[3 * i] = 0.0, io.terms[3 * i + 1] = 0.0, io.terms[3 * i + 2] = 0.0;
         io.links[i] = (uint8_t)NO_CHILD, io.links[n + i] = (uint8_t)NO_CHILD;
         return;
@@ -106,16 +109,13 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
     // (NO_CHILD if none).
     auto append = [&](bool want, unsigned kind, V3 o, V3 d, double pw, int prem) -> unsigned {
         unsigned oct = (d.x < 0.0 ? 1u : 0u) | (d.y < 0.0 ? 2u : 0u) | (d.z < 0.0 ? 4u : 0u);
-        if constexpr (DIR_BINS == 24) {
-            const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
-            oct = oct * 3u + (ax >= ay && ax >= az ? 0u : ay >= az ? 1u : 2u);
-        }
+        if constexpr (DIRS == 1) oct = 0u;
         unsigned k = 0, before = 0;
 #pragma unroll
-        for (unsigned b = 0; b < DIR_BINS; ++b) {
+        for (unsigned b = 0; b < DIRS; ++b) {
             const unsigned long long m = __ballot(want && oct == b);
             const unsigned n = (unsigned)__popcll(m);
-            if (lane == b) io.out_counts[(kind * DIR_BINS + b) * (io.waves + 1u) + wave] = n;
+            if (lane == b) io.out_counts[(kind * DIRS + b) * (io.waves + 1u) + wave] = n;
             if (oct == b) k = before + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             before += n;
         }
@@ -162,14 +162,14 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
 // that a wave's unit is uniform -- the counts then come through vector loads, +1.5 ms -- and one thread per (parent, bin)
 // writing its run serially, +3 ms.)
 __global__ __launch_bounds__(256) void level_index_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets, uint32_t waves,
-                                                          uint32_t *__restrict__ slot_of_ray, uint32_t *__restrict__ ray_of_slot) {
+                                                          uint32_t dirs, uint32_t *__restrict__ slot_of_ray, uint32_t *__restrict__ ray_of_slot) {
     // (readfirstlane: the unit is the same for a wave's 64 lanes, and saying so keeps the counts in scalar loads)
     const unsigned unit = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));  // (parent, kind)
     if (unit >= 2u * waves) return;
     const unsigned kind = unit >= waves ? 1u : 0u, p = unit - kind * waves, k = threadIdx.x & 63u;
     unsigned before = 0;
-    for (unsigned b = 0; b < DIR_BINS; ++b) {
-        const size_t at = (size_t)(kind * DIR_BINS + b) * (waves + 1u) + p;
+    for (unsigned b = 0; b < dirs; ++b) {
+        const size_t at = (size_t)(kind * dirs + b) * (waves + 1u) + p;
         const unsigned n = counts[at];
         if (k >= before && k < before + n) {
             const size_t slot = (size_t)kind * 64 * waves + (size_t)p * 64 + k;
@@ -237,7 +237,7 @@ hipError_t reserve(ArenaBuffer &b, size_t bytes) {
     return hipSuccess;
 }
 
-template <int NEST, bool TIES>
+template <int NEST, bool TIES, unsigned DIRS>
 hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows, int max_depth, double *rgb, LevelArena &A,
                          hipStream_t stream) {
 #define RT_TRY(expr)                       \
@@ -258,7 +258,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         const bool last = level == max_depth;  // its rays have no budget left: nothing is appended
         RT_TRY(reserve(A.terms[level], (size_t)waves * 64 * 3 * sizeof(double)));
         RT_TRY(reserve(A.links[level], (size_t)waves * 64 * 2));
-        const size_t table = ((size_t)waves + 1) * LEVEL_BINS;  // per bin: one count per wave and a last entry that stays zero
+        const size_t table = ((size_t)waves + 1) * 2 * DIRS;  // per bin: one count per wave and a last entry that stays zero
         if (table > 0x7fffffffull) return hipErrorInvalidValue;  // (the scan counts its items in an int)
         RT_TRY(reserve(A.counts, table * sizeof(uint32_t)));
         if (!last) {
@@ -281,8 +281,8 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         levels = level + 1;
         uint32_t *counts = (uint32_t *)A.counts.p, *offsets = (uint32_t *)A.offsets.p;
         if (!last) RT_TRY(hipMemsetAsync(counts, 0, table * sizeof(uint32_t), stream));  // (the last entry of every bin must read as zero)
-        if (level == 0) level_kernel<NEST, TIES, true><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
-        else level_kernel<NEST, TIES, false><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
+        if (level == 0) level_kernel<NEST, TIES, true, DIRS><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
+        else level_kernel<NEST, TIES, false, DIRS><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
         RT_TRY(hipGetLastError());
         if (last) break;
         // number the children: bin after bin, each bin in the order of the parent waves
@@ -297,7 +297,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         if (children == 0) break;
         if (children > 0x3fffffffull) return hipErrorOutOfMemory;
         RT_TRY(reserve(A.index, (size_t)children * sizeof(uint32_t)));
-        level_index_kernel<<<dim3((2 * waves + 3) / 4), 256, 0, stream>>>(counts, offsets, waves, (uint32_t *)A.index.p, (uint32_t *)A.ray_of_slot[level].p);
+        level_index_kernel<<<dim3((2 * waves + 3) / 4), 256, 0, stream>>>(counts, offsets, waves, DIRS, (uint32_t *)A.index.p, (uint32_t *)A.ray_of_slot[level].p);
         n_rays = (unsigned)children;
         waves = (n_rays + 63) / 64;
     }
@@ -379,9 +379,13 @@ hipError_t launch_render_levels(const DeviceScene &scene, const RtCameraDev &cam
         }
         rows.n_tiles = ((camera.hsize + 7) / 8) * ((rows.n_rows + 7) / 8);
         rows.tile_list = nullptr;
-        if (scene.any_order != 0 && scene.cone_nodes == 0) e = render_levels<2, true>(scene, camera, rows, max_depth, out, arena, stream);
-        else if (scene.any_order != 0) e = render_levels<1, true>(scene, camera, rows, max_depth, out, arena, stream);
-        else e = render_levels<1, false>(scene, camera, rows, max_depth, out, arena, stream);
+        const bool octants = scene.n_leaves >= LEVELS_OCTANT_MIN_LEAVES;  // (a property of the scene: the same for every launch)
+        const int build = scene.any_order != 0 && scene.cone_nodes == 0 ? 2 : scene.any_order != 0 ? 1 : 0;
+#define RT_LEVELS(N, T)                                                                                          \
+    (octants ? render_levels<N, T, 8>(scene, camera, rows, max_depth, out, arena, stream)                        \
+             : render_levels<N, T, 1>(scene, camera, rows, max_depth, out, arena, stream))
+        e = build == 2 ? RT_LEVELS(2, true) : build == 1 ? RT_LEVELS(1, true) : RT_LEVELS(1, false);
+#undef RT_LEVELS
     }
     if (e == hipSuccess && marks) e = hipEventRecord(marks[2], stream);
     return e;
