@@ -12,10 +12,10 @@
 //   level k > 0  one wave per 64 consecutive rays of the queue the level before wrote.
 //
 // A wave writes the reflection and refraction rays it spawns into slots of its own (64 per kind), counts them per
-// BIN -- kind x octant of the ray's direction, sixteen bins -- and an exclusive scan of the counts numbers the next
-// level's rays: bin after bin, each bin in the order of the parent waves -- screen order, roughly, at every level --
-// so a wave's 64 rays are of one kind, travel in one octant (the node tables are ordered front to back per octant)
-// and come from neighbouring pixels.  (Appending in the order in which waves happen to finish mixes rays from all over
+// BIN -- the kind, and for large hierarchies kind x octant of the ray's direction -- and an exclusive scan of the
+// counts numbers the next level's rays: bin after bin, each bin in the order of the parent waves -- screen order,
+// roughly, at every level -- so a wave's 64 rays are of one kind, come from neighbouring pixels and (with octant bins)
+// travel in one octant: the node tables are ordered front to back per octant.  (Appending in the order in which waves happen to finish mixes rays from all over
 // the frame: measured, the deeper levels then take three to four times as long.)
 //
 // Sums.  Each ray stores its term of its pixel's colour (path weight x surface colour, as in radiance()) under its own
@@ -40,9 +40,9 @@ constexpr int LEVELS_OCTANT_MIN_LEAVES = 2048;
 namespace {
 
 constexpr unsigned NO_CHILD = 0xffu;
-// Bins of a level's children: kind (reflection, refraction) x direction bin (DIRS = 8: the octant, bit a set: towards -a,
-// as in DeviceScene::oct_tables; DIRS = 1: none).
 
+// (Bins of a level's children, wherever DIRS appears below: kind -- reflection 0, refraction 1 -- x direction bin; DIRS = 8:
+// the octant, bit a set: towards -a, as in DeviceScene::oct_tables; DIRS = 1: no direction bins.)
 struct LevelIO {
     // the rays of this level (unused at level 0)
     const double *in_f = nullptr;       // eight doubles per slot, one 64-byte line: origin, direction, weight, remaining budget

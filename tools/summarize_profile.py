@@ -18,11 +18,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def device_source_hash() -> str:
-    """The same hash bench.py computes: identifies the kernel sources a PMC figure belongs to."""
+    """Identifies the kernel sources a PMC figure belongs to: a hash of their code, comments and blank space left out
+    (a reworded comment does not make a measurement stale)."""
     h = hashlib.sha256()
     for name in ("rt_device.hip", "rt_levels.inl", "rt_device_types.h", "rt_flatten.cpp"):
-        with open(os.path.join(ROOT, "raytracer_rs_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, "raytracer_rs_amd", "csrc", name), "r", encoding="utf-8") as f:
+            text = re.sub(r"/\*.*?\*/", " ", f.read(), flags=re.S)
+        for line in text.splitlines():
+            code = " ".join(line.split("//", 1)[0].split())
+            if code:
+                h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]
 
 
