@@ -695,9 +695,14 @@ class Canvas:
 
     def to_jpeg_bytes(self) -> bytes:
         """The file Canvas::to_jpeg writes (canvas.rs:92-114: quality 100 through the `image` crate's encoder), in memory."""
-        n = L.lib().rt_canvas_to_jpeg(self._ptr(), self.width, self.height, None, 0)
-        buf = C.create_string_buffer(n)
-        L.lib().rt_canvas_to_jpeg(self._ptr(), self.width, self.height, buf, n)
+        # one call when the file fits a buffer of the frame's raw size (it nearly always does); the call returns the
+        # length needed either way, and a second call follows only if it did not fit
+        cap = self.width * self.height * 3 + 4096
+        buf = C.create_string_buffer(cap)
+        n = L.lib().rt_canvas_to_jpeg(self._ptr(), self.width, self.height, buf, cap)
+        if n > cap:
+            buf = C.create_string_buffer(n)
+            L.lib().rt_canvas_to_jpeg(self._ptr(), self.width, self.height, buf, n)
         return buf.raw[:n]
 
     def to_jpeg(self, path: str) -> None:

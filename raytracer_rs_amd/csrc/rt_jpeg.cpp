@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/raytracer_rs_amd.h"
@@ -275,42 +276,68 @@ void canvas_to_jpeg(const double *rgb, uint32_t width, uint32_t height, std::str
     }
     static const Huffman luma_dc(LUMA_DC_LEN, DC_VAL), luma_ac(LUMA_AC_LEN, LUMA_AC_VAL), chroma_dc(CHROMA_DC_LEN, DC_VAL),
         chroma_ac(CHROMA_AC_LEN, CHROMA_AC_VAL);
-    // rows of the image as YCbCr bytes, eight rows at a time (Canvas::to_rgb_image's quantiser, canvas.rs:123-130, first)
-    std::vector<uint8_t> strip((size_t)8 * width * 3);
-    auto quantize = [](double value) -> uint8_t {
-        const double r = std::round(value * 255.0);
-        if (!(r > 0.0)) return 0;
-        if (r >= 255.0) return 255;
-        return (uint8_t)r;
+    // Transform first, code afterwards.  The strips of eight rows are independent up to the entropy coder -- canvas
+    // quantiser (Canvas::to_rgb_image, canvas.rs:123-130), YCbCr, the blocks' DCTs -- and go to up to eight threads;
+    // the coder itself runs over the finished coefficients in one pass (a block's DC is coded against the block before).
+    const uint32_t blocks_x = (width + 7) / 8, strips = (height + 7) / 8;
+    std::vector<int16_t> coded((size_t)blocks_x * strips * 3 * 64);  // |coefficient / 8| <= 1024
+    auto quantize = [](double value) -> uint8_t {  // (value * 255.0).round() saturated: see rt_canvas.cpp
+        const double x = value * 255.0;
+        if (!(x >= 0.5)) return 0;
+        if (x >= 254.5) return 255;
+        const uint32_t q = (uint32_t)x;
+        return (uint8_t)(q + (x - (double)q >= 0.5 ? 1u : 0u));
     };
-    BitWriter w(out);
-    int32_t prev[3] = {0, 0, 0};
-    uint8_t samples[3][64];
-    int32_t coeffs[64];
-    for (uint32_t y0 = 0; y0 < height; y0 += 8) {
-        for (uint32_t dy = 0; dy < 8; ++dy) {
-            const uint32_t y = y0 + dy < height ? y0 + dy : height - 1;  // edge pixels repeat beyond the border
-            const double *row = rgb + (size_t)y * width * 3;
-            uint8_t *dst = strip.data() + (size_t)dy * width * 3;
-            for (uint32_t x = 0; x < width; ++x)
-                rgb_to_ycbcr(quantize(row[x * 3]), quantize(row[x * 3 + 1]), quantize(row[x * 3 + 2]), dst[x * 3], dst[x * 3 + 1], dst[x * 3 + 2]);
-        }
-        for (uint32_t x0 = 0; x0 < width; x0 += 8) {
-            for (uint32_t dy = 0; dy < 8; ++dy)
-                for (uint32_t dx = 0; dx < 8; ++dx) {
-                    const uint32_t x = x0 + dx < width ? x0 + dx : width - 1;
-                    const uint8_t *p = strip.data() + ((size_t)dy * width + x) * 3;
-                    samples[0][dy * 8 + dx] = p[0];
-                    samples[1][dy * 8 + dx] = p[1];
-                    samples[2][dy * 8 + dx] = p[2];
+    auto transform = [&](uint32_t s0, uint32_t s1) {
+        std::vector<uint8_t> strip((size_t)8 * width * 3);
+        uint8_t samples[3][64];
+        int32_t coeffs[64];
+        for (uint32_t sy = s0; sy < s1; ++sy) {
+            const uint32_t y0 = sy * 8;
+            for (uint32_t dy = 0; dy < 8; ++dy) {
+                const uint32_t y = y0 + dy < height ? y0 + dy : height - 1;  // edge pixels repeat beyond the border
+                const double *row = rgb + (size_t)y * width * 3;
+                uint8_t *dst = strip.data() + (size_t)dy * width * 3;
+                for (uint32_t x = 0; x < width; ++x)
+                    rgb_to_ycbcr(quantize(row[x * 3]), quantize(row[x * 3 + 1]), quantize(row[x * 3 + 2]), dst[x * 3], dst[x * 3 + 1], dst[x * 3 + 2]);
+            }
+            for (uint32_t bx = 0; bx < blocks_x; ++bx) {
+                const uint32_t x0 = bx * 8;
+                for (uint32_t dy = 0; dy < 8; ++dy)
+                    for (uint32_t dx = 0; dx < 8; ++dx) {
+                        const uint32_t x = x0 + dx < width ? x0 + dx : width - 1;
+                        const uint8_t *p = strip.data() + ((size_t)dy * width + x) * 3;
+                        samples[0][dy * 8 + dx] = p[0];
+                        samples[1][dy * 8 + dx] = p[1];
+                        samples[2][dy * 8 + dx] = p[2];
+                    }
+                int16_t *dst = coded.data() + ((size_t)sy * blocks_x + bx) * 3 * 64;
+                for (int c = 0; c < 3; ++c) {
+                    fdct(samples[c], coeffs);
+                    for (int i = 0; i < 64; ++i) dst[c * 64 + i] = (int16_t)(coeffs[i] / 8);  // towards zero; then divided by the quantiser, which is 1
                 }
-            for (int c = 0; c < 3; ++c) {
-                fdct(samples[c], coeffs);
-                for (int i = 0; i < 64; ++i) coeffs[i] /= 8;  // towards zero; then divided by the quantiser, which is 1
-                prev[c] = write_block(w, coeffs, prev[c], c == 0 ? luma_dc : chroma_dc, c == 0 ? luma_ac : chroma_ac);
             }
         }
+    };
+    unsigned n_threads = (size_t)width * height < (1u << 18) ? 1u : std::thread::hardware_concurrency();
+    n_threads = n_threads == 0 ? 1 : n_threads > 8 ? 8 : n_threads;
+    if (n_threads == 1) {
+        transform(0, strips);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_threads; ++t)
+            pool.emplace_back(transform, (uint32_t)((uint64_t)strips * t / n_threads), (uint32_t)((uint64_t)strips * (t + 1) / n_threads));
+        for (std::thread &t : pool) t.join();
     }
+    BitWriter w(out);
+    int32_t prev[3] = {0, 0, 0};
+    int32_t block[64];
+    for (size_t b = 0; b < (size_t)blocks_x * strips; ++b)
+        for (int c = 0; c < 3; ++c) {
+            const int16_t *src = coded.data() + (b * 3 + c) * 64;
+            for (int i = 0; i < 64; ++i) block[i] = src[i];
+            prev[c] = write_block(w, block, prev[c], c == 0 ? luma_dc : chroma_dc, c == 0 ? luma_ac : chroma_ac);
+        }
     w.pad();
     out += "\xff\xd9";
 }
