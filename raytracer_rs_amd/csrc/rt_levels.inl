@@ -379,7 +379,11 @@ hipError_t launch_render_levels(const DeviceScene &scene, const RtCameraDev &cam
         }
         rows.n_tiles = ((camera.hsize + 7) / 8) * ((rows.n_rows + 7) / 8);
         rows.tile_list = nullptr;
-        const bool octants = scene.n_leaves >= LEVELS_OCTANT_MIN_LEAVES;  // (a property of the scene: the same for every launch)
+        // (a property of the scene: the same for every launch; RT_LEVELS_OCTANT_MIN_LEAVES in the environment moves the
+        // threshold, so that tests can put small worlds of every kind through the octant bins)
+        int octant_min = LEVELS_OCTANT_MIN_LEAVES;
+        if (const char *env = getenv("RT_LEVELS_OCTANT_MIN_LEAVES")) octant_min = atoi(env);
+        const bool octants = scene.n_leaves >= octant_min;
         const int build = scene.any_order != 0 && scene.cone_nodes == 0 ? 2 : scene.any_order != 0 ? 1 : 0;
 #define RT_LEVELS(N, T)                                                                                          \
     (octants ? render_levels<N, T, 8>(scene, camera, rows, max_depth, out, arena, stream)                        \

@@ -33,8 +33,11 @@ def _fetch(hip, ptr, shape, dtype):
     return out
 
 
+@pytest.mark.parametrize("octants", [False, True])
 @pytest.mark.parametrize("scene", ["chapter_12", "chapter_14"])
-def test_book_scenes_with_groups_level_by_level(gpu, rt, orc, levels, scene):
+def test_book_scenes_with_groups_level_by_level(gpu, rt, orc, levels, monkeypatch, scene, octants):
+    if octants:
+        monkeypatch.setenv("RT_LEVELS_OCTANT_MIN_LEAVES", "0")  # rays binned by direction octant too, as in large hierarchies
     cam, world, ocam, oworld = load_both(rt, orc, scene)
     s = world.scene()
     assert s.info().kernel_build == 3
@@ -49,13 +52,18 @@ def test_book_scenes_with_groups_level_by_level(gpu, rt, orc, levels, scene):
     assert np.array_equal(again, plain), "two renders of the same frame differ"
 
 
+@pytest.mark.parametrize("octants", [False, True])
 @pytest.mark.parametrize("seed,n_top", [(1, 6), (4, 6), (9, 6), (12, 6), (101, 25), (103, 60), (104, 90)])
-def test_random_worlds_level_by_level(gpu, rt, orc, levels, seed, n_top):
-    """Random hierarchies (every shape, cones under range-skip nodes, nested groups, patterns, glass and mirrors)."""
+def test_random_worlds_level_by_level(gpu, rt, orc, levels, monkeypatch, seed, n_top, octants):
+    """Random hierarchies (every shape, cones under range-skip nodes, nested groups, patterns, glass and mirrors), with
+    the next level's rays binned by kind alone (what worlds of this size get) and by kind and direction octant (what
+    large hierarchies get; RT_LEVELS_OCTANT_MIN_LEAVES=0 hands it to every world)."""
     import tomli
 
     from raytracer_rs_amd import synthetic
 
+    if octants:
+        monkeypatch.setenv("RT_LEVELS_OCTANT_MIN_LEAVES", "0")
     text = synthetic.random_scene(seed, 96, 64, n_top)
     sf = rt.SceneFile.from_str(text)
     cam, world = sf.build_camera(), sf.build_world()
