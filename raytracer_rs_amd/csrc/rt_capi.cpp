@@ -570,6 +570,9 @@ int rt_render(const rt_scene *scene_c, const rt_camera_desc *camera, const rt_re
     const uint32_t unit = banded ? rows.band_rows : 8u;
     uint32_t n_groups = (uint32_t)std::min<size_t>(RenderPipe::MAX_GROUPS, std::max<size_t>(1, bytes / (8u << 20)));
     const uint32_t units = (rows.n_rows + unit - 1) / unit;
+    // (a world rendered level by level pays six launches and five host round trips per group, and small groups leave its
+    // levels short of rays: four groups cost 4 % of the rendering time of an 8K frame, sixteen 36 %)
+    if (scene->by_levels && n_groups > 4) n_groups = 4;
     if (n_groups > units) n_groups = units;
     uint32_t begin[RenderPipe::MAX_GROUPS + 1];
     for (uint32_t g = 0; g <= n_groups; ++g) begin[g] = std::min<uint64_t>(rows.n_rows, (uint64_t)units * g / n_groups * unit);
