@@ -199,9 +199,11 @@ int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_rend
  * (row_end-row_begin)*hsize*3 doubles starting at row_begin, or with bands the selected bands one after another
  * (band_rows*hsize*3 doubles each, the frame's last band possibly shorter).  No host synchronisation unless
  * collect_stats is set -- or the world is a large hierarchy (rt_scene_info.kernel_build 3): such a world is rendered
- * level by level of its ray trees through ray queues in device memory, the call then waits on opts->stream once per
- * level to learn how many rays the next level has, and the handle allocates (and keeps) device memory that grows with
- * the frame, about 0.5 KB per pixel; the frame is complete in stream order when the call returns, as for any world.
+ * level by level of its ray trees through ray queues in device memory; the FIRST frame of a view (camera, rows, budget)
+ * waits on opts->stream once per level to learn how many rays the next level has and lets the handle allocate (and
+ * keep) device memory that grows with the frame, about 0.5 KB per pixel; the handle remembers the counts, and later
+ * frames of that view are launched without waiting, like any world's.  The frame is complete in stream order when
+ * the call returns, as for any world.
  * A handle serves ONE render at a time (as `&World` is borrowed for the duration of Camera::render): the scratch in
  * which a launch orders its tiles, the counters and the timing marks belong to the handle, which is `const` here only
  * in the sense that the world it holds does not change.  Launches of one handle on one stream are ordered by the

@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "../../include/raytracer_rs_amd.h"

@@ -57,6 +57,21 @@ struct LevelArena {
     uint32_t *host_totals = nullptr;        // pinned: the level's child totals as the host reads them
     uint32_t levels = 0;                    // of the last frame: levels rendered, rays per level
     uint32_t level_rays[LEVELS_MAX] = {};
+    // How many rays each level of a frame has, remembered per view (camera, rows, budget): the scene behind a handle
+    // never changes, so the same view has the same ray trees, and a frame whose counts are known is launched without
+    // waiting for the GPU between levels.  A few entries, least recently used first to go.
+    struct Known {
+        RtCameraDev cam;
+        uint32_t rows[5];
+        int32_t max_depth;
+        uint32_t levels;
+        uint32_t level_rays[LEVELS_MAX];
+        uint64_t used;
+    };
+    static constexpr int KNOWN_MAX = 32;
+    Known known[KNOWN_MAX] = {};
+    uint32_t n_known = 0;
+    uint64_t clock = 0;
     size_t device_bytes() const;
 };
 void level_arena_release(LevelArena &arena);

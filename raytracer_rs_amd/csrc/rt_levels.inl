@@ -250,6 +250,17 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
     const unsigned blocks_x = (tiles_x + 7) / 8, blocks_y = (tiles_y + 7) / 8;
     if ((unsigned long long)blocks_x * blocks_y * 64 > 0x00ffffffull) return hipErrorInvalidValue;  // 2^24 waves: 2^31 queue slots
     if (!A.host_totals) RT_TRY(hipHostMalloc((void **)&A.host_totals, 2 * sizeof(uint32_t), 0));
+    // Seen this view before?  Then every level's ray count is known and nothing below waits for the GPU.
+    LevelArena::Known *known = nullptr;
+    const uint32_t view[5] = {rows.row_begin, rows.row_end, rows.n_rows, rows.band_rows, rows.band_pitch};
+    const char *remember_env = getenv("RT_LEVELS_REMEMBER");  // =0: always ask the GPU (tests compare the two)
+    const bool remember = !(remember_env && remember_env[0] == '0');
+    for (uint32_t k = 0; remember && k < A.n_known; ++k)
+        if (A.known[k].max_depth == max_depth && std::memcmp(&A.known[k].cam, &camera, sizeof camera) == 0 &&
+            std::memcmp(A.known[k].rows, view, sizeof view) == 0) {
+            known = &A.known[k];
+            known->used = ++A.clock;
+        }
     const size_t lds = lds_bytes<NEST, false>(64);
     unsigned waves = blocks_x * blocks_y * 64, n_rays = waves * 64, levels = 0;
     uint32_t level_waves[LEVELS_MAX] = {};
@@ -291,9 +302,14 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         RT_TRY(reserve(A.scan_temp, need));
         size_t bytes = A.scan_temp.bytes;
         RT_TRY(hipcub::DeviceScan::ExclusiveSum(A.scan_temp.p, bytes, counts, offsets, (int)table, stream));
-        RT_TRY(hipMemcpyAsync(A.host_totals, offsets + table - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        RT_TRY(hipStreamSynchronize(stream));
-        const unsigned long long children = A.host_totals[0];
+        unsigned long long children;
+        if (known) {
+            children = (uint32_t)level + 1 < known->levels ? known->level_rays[level + 1] : 0;
+        } else {
+            RT_TRY(hipMemcpyAsync(A.host_totals, offsets + table - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            RT_TRY(hipStreamSynchronize(stream));
+            children = A.host_totals[0];
+        }
         if (children == 0) break;
         if (children > 0x3fffffffull) return hipErrorOutOfMemory;
         RT_TRY(reserve(A.index, (size_t)children * sizeof(uint32_t)));
@@ -309,6 +325,23 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
     }
     level_store_kernel<<<dim3(level_waves[0]), 64, 0, stream>>>(camera, rows, (const double *)A.terms[0].p, level_waves[0], blocks_x, rgb);
     A.levels = levels;
+    if (!known && remember) {  // remember this view's counts (in place of the entry unused for longest when all are taken)
+        uint32_t at = A.n_known;
+        if (at == LevelArena::KNOWN_MAX) {
+            at = 0;
+            for (uint32_t k = 1; k < A.n_known; ++k)
+                if (A.known[k].used < A.known[at].used) at = k;
+        } else {
+            A.n_known++;
+        }
+        LevelArena::Known &e = A.known[at];
+        std::memcpy(&e.cam, &camera, sizeof camera);
+        std::memcpy(e.rows, view, sizeof view);
+        e.max_depth = max_depth;
+        e.levels = levels;
+        std::memcpy(e.level_rays, A.level_rays, sizeof e.level_rays);
+        e.used = ++A.clock;
+    }
     return hipGetLastError();
 #undef RT_TRY
 }

@@ -156,6 +156,42 @@ def test_large_frames_are_rendered_in_chunks_of_rows(gpu, rt, orc, levels, monke
         hip.hipFree(buf)
 
 
+def test_repeated_views_are_launched_from_remembered_counts(gpu, rt, orc, levels, monkeypatch):
+    """The first frame of a view asks the GPU after every level how many rays the next one has; the handle remembers the
+    answers per view (camera, rows, budget) and launches later frames of that view without waiting.  Views alternating
+    through one handle -- two frame sizes, a row range, bands, another budget, more views than the handle remembers --
+    must come out as they do when nothing is remembered (RT_LEVELS_REMEMBER=0)."""
+    hip = _hip()
+    sf = rt.SceneFile.from_file(scene_path("chapter_14"))
+    world = sf.build_world()
+    s = world.scene()
+    cams = [sf.build_camera(160, 96), sf.build_camera(203, 131)]
+    views = [(cams[0], {}), (cams[1], {}), (cams[0], {"rows": (8, 40)}), (cams[1], {"max_depth": 2}), (cams[0], {"rows": (0, 96)})]
+    views += [(cams[0], {"rows": (k, k + 8)}) for k in range(0, 88, 2)]  # 44 more: beyond what a handle remembers
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), 203 * 131 * 24) == 0
+
+    def frame(cam, kw):
+        rows = kw.get("rows", (0, cam.vsize))
+        s.render_device(cam, buf.value, **kw)
+        return _fetch(hip, buf, (rows[1] - rows[0], cam.hsize, 3), np.float64)
+
+    try:
+        monkeypatch.setenv("RT_LEVELS_REMEMBER", "0")
+        want = [frame(cam, kw) for cam, kw in views]
+        monkeypatch.delenv("RT_LEVELS_REMEMBER")
+        for _ in range(3):  # first pass fills the memory, later passes use it (and evict and refill part of it)
+            for (cam, kw), ref in zip(views, want):
+                assert np.array_equal(frame(cam, kw), ref), kw
+        bands = np.zeros((96, 160, 3))
+        for _ in range(2):
+            for r in range(3):
+                s.render(cams[0], bands=(16, r, 3), out=bands)
+            assert np.array_equal(bands, want[0])
+    finally:
+        hip.hipFree(buf)
+
+
 def test_several_workers_level_by_level(gpu, rt, orc, levels):
     """rt_multi_* over a world rendered level by level: workers, units and stripes as for any world; the frame is the
     single-handle frame bit for bit (f64 in device memory, 8-bit, host), the counters are the counting kernel's."""
