@@ -161,7 +161,7 @@ typedef struct rt_scene_info {
     int32_t kernel_build; /* which build of the render kernel serves this world: 0 = a table of leaves only (no groups, at
                              most 12 objects), 1 = any table, 2 = a table in which no range of nodes holds a cone,
                              3 = a large hierarchy, rendered level by level of its ray trees through queues in device
-                             memory (rt_render_device_noalloc refuses such a world) */
+                             memory (rt_render_device_noalloc serves such a world only for views rendered before) */
 } rt_scene_info;
 
 /* struct Computations (rendering/intersections.rs:12-24); `object` is an index into rt_world_desc.objects. */
@@ -222,7 +222,11 @@ int rt_render_device(const rt_scene *scene, const rt_camera_desc *camera, const 
  * RT_RENDER_TIMED are refused (RT_ERR_INVALID_ARGUMENT: they need a host synchronisation resp. event creation).
  * All calls on one GPU -- through any scene handle -- share that GPU's array: calls that overlap in time on one GPU
  * race on the tile order (the caller serialises them, e.g. by using one stream); the array keeps the last call's
- * contents and every call rewrites what it reads. */
+ * contents and every call rewrites what it reads.
+ * A world rendered level by level (rt_scene_info.kernel_build 3) does not use the static array: its frames go through
+ * ray queues that the handle owns.  For such a world the call is served -- again without allocating or waiting -- for
+ * a view (camera, rows, depth) that rt_render_device has rendered on this handle before, and refused with
+ * RT_ERR_UNSUPPORTED otherwise (a view's first frame sizes the queues and learns its ray counts from the GPU). */
 #define RT_NOALLOC_MAX_TILES 524288u
 #define RT_NOALLOC_SCRATCH_BYTES ((256u + 3u * RT_NOALLOC_MAX_TILES) * 4u)
 int rt_render_device_noalloc(const rt_scene *scene, const rt_camera_desc *camera, const rt_render_opts *opts,

@@ -471,9 +471,25 @@ int rt_render_device_noalloc(const rt_scene *scene, const rt_camera_desc *camera
         return set_error(RT_ERR_INVALID_ARGUMENT, "rt_render_device_noalloc cannot collect stats (that needs a host synchronisation)");
     if (opts && (opts->flags & RT_RENDER_TIMED))
         return set_error(RT_ERR_INVALID_ARGUMENT, "rt_render_device_noalloc cannot time the launch (that needs event creation)");
-    if (scene->by_levels)
-        return set_error(RT_ERR_UNSUPPORTED, "this world is rendered level by level (rt_scene_info.kernel_build 3), through ray queues in device memory "
-                                             "that grow with the frame; rt_render_device_noalloc cannot serve it (use rt_render_device)");
+    if (scene->by_levels) {
+        // A world rendered level by level needs ray queues that grow with the frame and, for a view it has not rendered
+        // before, a wait after every level.  Neither is allowed here: the call is served only when this very view has
+        // been rendered through rt_render_device on this handle before (its counts are remembered, its buffers there).
+        hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
+        DeviceGuard guard(scene->device);
+        if (guard.status != hipSuccess) return hip_error(guard.status, "hipSetDevice");
+        if (opts && (opts->flags & RT_RENDER_QUANTIZED)) rows.quantized = reinterpret_cast<uint8_t *>(rgb_device);
+        rt::LevelArena &arena = const_cast<rt_scene *>(scene)->levels;  // one render at a time per handle
+        arena.frozen = true;
+        const hipError_t e = rt::launch_render_levels(scene->dev, cam, rows, depth, rgb_device, arena, stream, nullptr);
+        arena.frozen = false;
+        if (e == hipErrorNotReady)
+            return set_error(RT_ERR_UNSUPPORTED, "this world is rendered level by level (rt_scene_info.kernel_build 3), through ray queues in device memory "
+                                                 "that grow with the frame: rt_render_device_noalloc serves it only for a view (camera, rows, depth) that "
+                                                 "rt_render_device has rendered on this handle before");
+        HIP_TRY(e);
+        return RT_OK;
+    }
     const unsigned long long tiles = (unsigned long long)((camera->hsize + 7) / 8) * ((rows.n_rows + 7) / 8);
     if (tiles > RT_NOALLOC_MAX_TILES)
         return set_error(RT_ERR_CAPACITY, "the rows to render cover " + std::to_string(tiles) + " 8x8-pixel tiles; rt_render_device_noalloc's static scratch holds " +

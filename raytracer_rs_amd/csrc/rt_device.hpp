@@ -72,6 +72,9 @@ struct LevelArena {
     Known known[KNOWN_MAX] = {};
     uint32_t n_known = 0;
     uint64_t clock = 0;
+    // Set by a caller that must not allocate or wait (rt_render_device_noalloc) for the duration of its call: a frame
+    // whose view is not remembered, or whose buffers would have to grow, is then refused (hipErrorNotReady) instead.
+    bool frozen = false;
     size_t device_bytes() const;
 };
 void level_arena_release(LevelArena &arena);

@@ -222,8 +222,9 @@ __global__ __launch_bounds__(64) void level_store_kernel(RtCameraDev cam, RowMap
     store_tile(cam, rows, tile, lane, valid, x, r, y, acc, staging, rgb);
 }
 
-hipError_t reserve(ArenaBuffer &b, size_t bytes) {
+hipError_t reserve(ArenaBuffer &b, size_t bytes, bool frozen) {
     if (b.bytes >= bytes) return hipSuccess;
+    if (frozen) return hipErrorNotReady;  // (the caller must not allocate)
     if (b.p) {
         hipError_t e = hipFree(b.p);  // (waits for the device: nothing in flight reads it afterwards)
         b.p = nullptr;
@@ -249,7 +250,10 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
     const unsigned tiles_x = (camera.hsize + 7) / 8, tiles_y = (rows.n_rows + 7) / 8;
     const unsigned blocks_x = (tiles_x + 7) / 8, blocks_y = (tiles_y + 7) / 8;
     if ((unsigned long long)blocks_x * blocks_y * 64 > 0x00ffffffull) return hipErrorInvalidValue;  // 2^24 waves: 2^31 queue slots
-    if (!A.host_totals) RT_TRY(hipHostMalloc((void **)&A.host_totals, 2 * sizeof(uint32_t), 0));
+    if (!A.host_totals) {
+        if (A.frozen) return hipErrorNotReady;
+        RT_TRY(hipHostMalloc((void **)&A.host_totals, 2 * sizeof(uint32_t), 0));
+    }
     // Seen this view before?  Then every level's ray count is known and nothing below waits for the GPU.
     LevelArena::Known *known = nullptr;
     const uint32_t view[5] = {rows.row_begin, rows.row_end, rows.n_rows, rows.band_rows, rows.band_pitch};
@@ -261,21 +265,22 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
             known = &A.known[k];
             known->used = ++A.clock;
         }
+    if (A.frozen && !known) return hipErrorNotReady;  // (learning a view's ray counts means waiting for the GPU)
     const size_t lds = lds_bytes<NEST, false>(64);
     unsigned waves = blocks_x * blocks_y * 64, n_rays = waves * 64, levels = 0;
     uint32_t level_waves[LEVELS_MAX] = {};
     for (int level = 0; level <= max_depth; ++level) {
         const int out = level & 1, in = out ^ 1;
         const bool last = level == max_depth;  // its rays have no budget left: nothing is appended
-        RT_TRY(reserve(A.terms[level], (size_t)waves * 64 * 3 * sizeof(double)));
-        RT_TRY(reserve(A.links[level], (size_t)waves * 64 * 2));
+        RT_TRY(reserve(A.terms[level], (size_t)waves * 64 * 3 * sizeof(double), A.frozen));
+        RT_TRY(reserve(A.links[level], (size_t)waves * 64 * 2, A.frozen));
         const size_t table = ((size_t)waves + 1) * 2 * DIRS;  // per bin: one count per wave and a last entry that stays zero
         if (table > 0x7fffffffull) return hipErrorInvalidValue;  // (the scan counts its items in an int)
-        RT_TRY(reserve(A.counts, table * sizeof(uint32_t)));
+        RT_TRY(reserve(A.counts, table * sizeof(uint32_t), A.frozen));
         if (!last) {
-            RT_TRY(reserve(A.queue_f[out], (size_t)waves * 128 * 8 * sizeof(double)));
-            RT_TRY(reserve(A.offsets, table * sizeof(uint32_t)));
-            RT_TRY(reserve(A.ray_of_slot[level], (size_t)waves * 128 * sizeof(uint32_t)));
+            RT_TRY(reserve(A.queue_f[out], (size_t)waves * 128 * 8 * sizeof(double), A.frozen));
+            RT_TRY(reserve(A.offsets, table * sizeof(uint32_t), A.frozen));
+            RT_TRY(reserve(A.ray_of_slot[level], (size_t)waves * 128 * sizeof(uint32_t), A.frozen));
         }
         LevelIO io;
         io.in_f = (const double *)A.queue_f[in].p;
@@ -299,7 +304,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         // number the children: bin after bin, each bin in the order of the parent waves
         size_t need = 0;
         RT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, counts, offsets, (int)table, stream));
-        RT_TRY(reserve(A.scan_temp, need));
+        RT_TRY(reserve(A.scan_temp, need, A.frozen));
         size_t bytes = A.scan_temp.bytes;
         RT_TRY(hipcub::DeviceScan::ExclusiveSum(A.scan_temp.p, bytes, counts, offsets, (int)table, stream));
         unsigned long long children;
@@ -312,7 +317,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         }
         if (children == 0) break;
         if (children > 0x3fffffffull) return hipErrorOutOfMemory;
-        RT_TRY(reserve(A.index, (size_t)children * sizeof(uint32_t)));
+        RT_TRY(reserve(A.index, (size_t)children * sizeof(uint32_t), A.frozen));
         level_index_kernel<<<dim3((2 * waves + 3) / 4), 256, 0, stream>>>(counts, offsets, waves, DIRS, (uint32_t *)A.index.p, (uint32_t *)A.ray_of_slot[level].p);
         n_rays = (unsigned)children;
         waves = (n_rays + 63) / 64;

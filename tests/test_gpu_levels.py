@@ -218,11 +218,35 @@ def test_several_workers_level_by_level(gpu, rt, orc, levels):
         hip.hipFree(buf)
 
 
-def test_noalloc_entry_point_refuses_worlds_rendered_by_levels(gpu, rt, orc, levels):
-    cam, world, _, _ = load_both(rt, orc, "chapter_14", 64, 48)
-    with pytest.raises(rt.RtError) as e:
-        world.scene().render_device_noalloc(cam, 4096)  # refused before anything is launched: the pointer is never used
-    assert e.value.code == -7 and "level by level" in e.value.message
+def test_noalloc_entry_point_wants_the_view_rendered_before(gpu, rt, orc, levels):
+    """A world rendered level by level needs queues that grow with the frame and, for a new view, a wait per level:
+    rt_render_device_noalloc refuses a view the handle has not rendered (RT_ERR_UNSUPPORTED, nothing launched) and
+    serves it afterwards, with rt_render_device's bytes (tests/test_zz_no_alloc.py proves that it then allocates nothing)."""
+    hip = _hip()
+    w, h = 160, 96
+    cam, world, _, _ = load_both(rt, orc, "chapter_14", w, h)
+    s = world.scene()
+    a, b = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(a), w * h * 24) == 0 and hip.hipMalloc(ctypes.byref(b), w * h * 24) == 0
+    try:
+        with pytest.raises(rt.RtError) as e:
+            s.render_device_noalloc(cam, b.value)
+        assert e.value.code == -7 and "level by level" in e.value.message
+        s.render_device(cam, a.value)
+        want = _fetch(hip, a, (h, w, 3), np.float64)
+        s.render_device_noalloc(cam, b.value)
+        assert np.array_equal(_fetch(hip, b, (h, w, 3), np.float64), want)
+        with pytest.raises(rt.RtError):  # other rows are another view
+            s.render_device_noalloc(cam, b.value, rows=(8, 40))
+        s.render_device(cam, a.value, rows=(8, 40))
+        s.render_device_noalloc(cam, b.value, rows=(8, 40))
+        assert np.array_equal(_fetch(hip, b, (32, w, 3), np.float64), want[8:40])
+        s.render_device(cam, a.value, quantized=True)  # (the same view: what is stored does not change the ray counts)
+        s.render_device_noalloc(cam, b.value, quantized=True)
+        assert np.array_equal(_fetch(hip, b, (h, w, 3), np.uint8), orc.quantize(want))
+    finally:
+        hip.hipFree(a)
+        hip.hipFree(b)
 
 
 def test_deep_trees_and_empty_levels(gpu, rt, orc, levels):

@@ -159,3 +159,65 @@ def test_noalloc_entry_point_allocates_nothing(gpu, rt, orc):
         lib.hipStreamDestroy(stream)
         lib.hipFree(a)
         lib.hipFree(b)
+
+
+def test_noalloc_entry_point_allocates_nothing_level_by_level(gpu, rt, orc, monkeypatch):
+    """The same property for a world rendered level by level of its ray trees (forced here onto chapter_14; large
+    hierarchies take that path by themselves): once rt_render_device has rendered a view -- its ray counts are then
+    remembered and its queues exist -- rt_render_device_noalloc renders that view without allocating (hipMemGetInfo) and
+    without waiting for the GPU (it can be captured into a HIP graph in global capture mode), with the same bytes."""
+    monkeypatch.setenv("RT_RENDER_LEVELS", "1")
+    hip = Hip()
+    lib = hip.lib
+    lib.hipMemGetInfo.argtypes = [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    lib.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    lib.hipStreamBeginCapture.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.hipStreamEndCapture.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    lib.hipGraphInstantiate.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.hipGraphLaunch.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    lib.hipGraphExecDestroy.argtypes = [ctypes.c_void_p]
+    lib.hipGraphDestroy.argtypes = [ctypes.c_void_p]
+    lib.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    w, h = 640, 360
+    a, b = hip.alloc(w * h * 24), hip.alloc(w * h * 24)
+    stream = ctypes.c_void_p()
+    assert lib.hipStreamCreate(ctypes.byref(stream)) == 0
+    try:
+        cam, world, _, _ = load_both(rt, orc, "chapter_14", w, h)
+        scene = world.scene()
+        assert scene.info().kernel_build == 3
+        scene.render_device(cam, a.value, stream=stream.value)  # the view's first frame: counts learnt, queues made
+        want = hip.fetch(a, (h, w, 3), np.float64)
+        scene.render_device_noalloc(cam, b.value, stream=stream.value)  # (first use of the entry point on this stream)
+        assert lib.hipDeviceSynchronize() == 0
+        free0, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert lib.hipMemGetInfo(ctypes.byref(free0), ctypes.byref(total)) == 0
+        for _ in range(3):
+            scene.render_device_noalloc(cam, b.value, stream=stream.value)
+        assert lib.hipStreamSynchronize(stream) == 0
+        free1 = ctypes.c_size_t()
+        assert lib.hipMemGetInfo(ctypes.byref(free1), ctypes.byref(total)) == 0
+        assert free1.value == free0.value, "device memory was allocated during rt_render_device_noalloc"
+        assert np.array_equal(hip.fetch(b, (h, w, 3), np.float64), want)
+        assert lib.hipMemset(b, 0, w * h * 24) == 0 and lib.hipDeviceSynchronize() == 0
+        graph, graph_exec = ctypes.c_void_p(), ctypes.c_void_p()
+        assert lib.hipStreamBeginCapture(stream, 0) == 0  # hipStreamCaptureModeGlobal
+        try:
+            scene.render_device_noalloc(cam, b.value, stream=stream.value)
+        finally:
+            rc = lib.hipStreamEndCapture(stream, ctypes.byref(graph))
+        assert rc == 0 and graph.value, f"the capture was invalidated (hipStreamEndCapture: {rc})"
+        assert lib.hipGraphInstantiate(ctypes.byref(graph_exec), graph, None, None, 0) == 0
+        for _ in range(2):
+            assert lib.hipMemset(b, 0, w * h * 24) == 0 and lib.hipDeviceSynchronize() == 0
+            assert lib.hipGraphLaunch(graph_exec, stream) == 0
+            assert lib.hipStreamSynchronize(stream) == 0
+            assert np.array_equal(hip.fetch(b, (h, w, 3), np.float64), want)
+        lib.hipGraphExecDestroy(graph_exec)
+        lib.hipGraphDestroy(graph)
+    finally:
+        lib.hipStreamDestroy(stream)
+        lib.hipFree(a)
+        lib.hipFree(b)
+
