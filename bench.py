@@ -146,7 +146,7 @@ def committed_pmc(config: str) -> dict:
 def kernel_name(scene) -> str:
     info = scene.info()
     return {0: "render_kernel<false, 0, false>", 2: "render_kernel<false, 2, true>",
-            3: "level_kernel<1, true, *> (one launch per level of the ray trees, plus scans, numbering and sums)"}.get(
+            3: "level_kernel (one launch per level of the ray trees, plus sums; scans and numbering for a view's first frame)"}.get(
                 info.kernel_build, "render_kernel<false, 1, true>")
 
 

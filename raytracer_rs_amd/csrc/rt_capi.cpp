@@ -73,14 +73,14 @@ struct rt_scene_file {
 
 namespace {
 
-// Which worlds are rendered level by level: those with groups and at least RT_LEVELS_MIN_LEAVES leaves.  Measured on
-// MI355X at 3840x2160: generated hierarchies of 901 / 2 501 / 10 001 leaves render 35 % / 18 % / 30 % faster that way
-// (the single launch waits for its longest waves there), chapter_14 (327 leaves) 1 % faster, and frames of a few
-// thousand pixels slower (six launches instead of one).  A level render blocks the caller once per level and needs
-// device memory that grows with the frame, so small worlds keep the single launch.  RT_RENDER_LEVELS=0 / 1 in the
-// environment, read when a scene is created, forces the choice for every world with groups (worlds without groups
-// always take the single launch).
-constexpr uint32_t RT_LEVELS_MIN_LEAVES = 512;
+// Which worlds are rendered level by level (rt::launch_render_levels): every world with groups.  Measured on MI355X, GPU
+// time per frame of a repeated view, single launch / levels: chapter_14 (327 leaves) 1.70 / 0.80 ms at 320x200, 2.06 /
+// 1.16 at 1280x720, 4.47 / 4.18 at 3840x2160; generated hierarchies of 101 ... 10 001 leaves at 3840x2160 between 6 % and
+// 36 % faster (the single launch waits for its longest waves: the tiles whose 64 ray trees are all deep).  The price: a
+// view's first frame waits for the GPU after every level, and the handle keeps ray queues that grow with the frame.
+// RT_RENDER_LEVELS=0 / 1 in the environment, read when a scene is created, forces the choice for every world with groups
+// (worlds without groups always take the single launch); RT_LEVELS_MIN_LEAVES is there should small worlds ever need it.
+constexpr uint32_t RT_LEVELS_MIN_LEAVES = 0;
 bool render_by_levels(int max_nesting, uint32_t n_leaves) {
     if (max_nesting <= 0) return false;
     const char *e = getenv("RT_RENDER_LEVELS");

@@ -49,7 +49,7 @@ constexpr int LEVELS_MAX = RT_MAX_DEPTH + 1;  // level 0 = the rays through the 
 struct LevelArena {
     ArenaBuffer queue_f[2];                // the rays a level reads and the rays it writes: 64 bytes each (origin, direction, weight, remaining budget)
     ArenaBuffer counts, offsets;           // children per bin and wave of the level being rendered, and the same scanned
-    ArenaBuffer index;                     // ray number in the next level -> its slot in the queue
+    ArenaBuffer index[LEVELS_MAX];         // per level: ray number in the next level -> its slot in the queue
     ArenaBuffer ray_of_slot[LEVELS_MAX];   // the other way round, per level (kept for the sums: where a ray's children are)
     ArenaBuffer terms[LEVELS_MAX];         // per ray of a level: its term of its pixel's sum, then the sum over its subtree
     ArenaBuffer links[LEVELS_MAX];         // per ray of a level: which of its wave's children are its own
@@ -75,6 +75,10 @@ struct LevelArena {
     // Set by a caller that must not allocate or wait (rt_render_device_noalloc) for the duration of its call: a frame
     // whose view is not remembered, or whose buffers would have to grow, is then refused (hipErrorNotReady) instead.
     bool frozen = false;
+    // Which remembered view the numbering in index[] / ray_of_slot[] belongs to (-1: none).  The numbering of a view's
+    // rays is the same in every frame, so a frame of the view rendered last skips the counting, the scans and the
+    // numbering kernels altogether.
+    int32_t numbered = -1;
     size_t device_bytes() const;
 };
 void level_arena_release(LevelArena &arena);

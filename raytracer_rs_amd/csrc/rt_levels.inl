@@ -50,7 +50,8 @@ struct LevelIO {
     uint32_t n_rays = 0;
     // what it writes
     double *out_f = nullptr;            // 128 slots per wave: kind * 64 * waves + wave * 64 + k
-    uint32_t *out_counts = nullptr;     // [2 * DIRS][waves + 1]: children per bin (kind * DIRS + direction bin) and wave
+    uint32_t *out_counts = nullptr;     // [2 * DIRS][waves + 1]: children per bin (kind * DIRS + direction bin) and wave;
+                                        // nullptr: not wanted (the numbering of this view's rays is in place already)
     uint32_t waves = 0;
     double *terms = nullptr;            // three doubles per ray
     uint8_t *links = nullptr;           // two arrays of 64 * waves bytes: k of the ray's reflection / refraction, or NO_CHILD
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
     }
     if (FIRST && __ballot(have) == 0ull) {  // a tile outside the frame (the launch is padded to whole blocks of tiles)
         const size_t n = (size_t)io.waves * 64, i = (size_t)wave * 64 + lane;
-        if (lane < 2u * DIRS) io.out_counts[lane * (io.waves + 1u) + wave] = 0u;
+        if (io.out_counts && lane < 2u * DIRS) io.out_counts[lane * (io.waves + 1u) + wave] = 0u;
         io.terms[3 * i] = 0.0, io.terms[3 * i + 1] = 0.0, io.terms[3 * i + 2] = 0.0;
         io.links[i] = (uint8_t)NO_CHILD, io.links[n + i] = (uint8_t)NO_CHILD;
         return;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
         for (unsigned b = 0; b < DIRS; ++b) {
             const unsigned long long m = __ballot(want && oct == b);
             const unsigned n = (unsigned)__popcll(m);
-            if (lane == b) io.out_counts[(kind * DIRS + b) * (io.waves + 1u) + wave] = n;
+            if (io.out_counts && lane == b) io.out_counts[(kind * DIRS + b) * (io.waves + 1u) + wave] = n;
             if (oct == b) k = before + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             before += n;
         }
@@ -266,6 +267,9 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
             known->used = ++A.clock;
         }
     if (A.frozen && !known) return hipErrorNotReady;  // (learning a view's ray counts means waiting for the GPU)
+    // The view rendered last?  Then its rays' numbering is still in the arena, and it is the same in every frame.
+    const bool numbered = known && A.numbered == (int32_t)(known - A.known);
+    if (!numbered) A.numbered = -1;  // (about to be overwritten)
     const size_t lds = lds_bytes<NEST, false>(64);
     unsigned waves = blocks_x * blocks_y * 64, n_rays = waves * 64, levels = 0;
     uint32_t level_waves[LEVELS_MAX] = {};
@@ -284,10 +288,10 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         }
         LevelIO io;
         io.in_f = (const double *)A.queue_f[in].p;
-        io.in_index = (const uint32_t *)A.index.p;
+        io.in_index = level == 0 ? nullptr : (const uint32_t *)A.index[level - 1].p;
         io.n_rays = n_rays;
         io.out_f = (double *)A.queue_f[out].p;
-        io.out_counts = (uint32_t *)A.counts.p;
+        io.out_counts = numbered ? nullptr : (uint32_t *)A.counts.p;
         io.waves = waves;
         io.terms = (double *)A.terms[level].p;
         io.links = (uint8_t *)A.links[level].p;
@@ -296,11 +300,17 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         A.level_rays[level] = n_rays;
         levels = level + 1;
         uint32_t *counts = (uint32_t *)A.counts.p, *offsets = (uint32_t *)A.offsets.p;
-        if (!last) RT_TRY(hipMemsetAsync(counts, 0, table * sizeof(uint32_t), stream));  // (the last entry of every bin must read as zero)
+        if (!last && !numbered) RT_TRY(hipMemsetAsync(counts, 0, table * sizeof(uint32_t), stream));  // (the last entry of every bin must read as zero)
         if (level == 0) level_kernel<NEST, TIES, true, DIRS><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
         else level_kernel<NEST, TIES, false, DIRS><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
         RT_TRY(hipGetLastError());
         if (last) break;
+        if (numbered) {
+            if ((uint32_t)level + 1 >= known->levels) break;
+            n_rays = known->level_rays[level + 1];
+            waves = (n_rays + 63) / 64;
+            continue;
+        }
         // number the children: bin after bin, each bin in the order of the parent waves
         size_t need = 0;
         RT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, counts, offsets, (int)table, stream));
@@ -317,8 +327,9 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         }
         if (children == 0) break;
         if (children > 0x3fffffffull) return hipErrorOutOfMemory;
-        RT_TRY(reserve(A.index, (size_t)children * sizeof(uint32_t), A.frozen));
-        level_index_kernel<<<dim3((2 * waves + 3) / 4), 256, 0, stream>>>(counts, offsets, waves, DIRS, (uint32_t *)A.index.p, (uint32_t *)A.ray_of_slot[level].p);
+        RT_TRY(reserve(A.index[level], (size_t)children * sizeof(uint32_t), A.frozen));
+        level_index_kernel<<<dim3((2 * waves + 3) / 4), 256, 0, stream>>>(counts, offsets, waves, DIRS, (uint32_t *)A.index[level].p,
+                                                                          (uint32_t *)A.ray_of_slot[level].p);
         n_rays = (unsigned)children;
         waves = (n_rays + 63) / 64;
     }
@@ -330,6 +341,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
     }
     level_store_kernel<<<dim3(level_waves[0]), 64, 0, stream>>>(camera, rows, (const double *)A.terms[0].p, level_waves[0], blocks_x, rgb);
     A.levels = levels;
+    if (known) A.numbered = (int32_t)(known - A.known);
     if (!known && remember) {  // remember this view's counts (in place of the entry unused for longest when all are taken)
         uint32_t at = A.n_known;
         if (at == LevelArena::KNOWN_MAX) {
@@ -346,6 +358,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         e.levels = levels;
         std::memcpy(e.level_rays, A.level_rays, sizeof e.level_rays);
         e.used = ++A.clock;
+        A.numbered = (int32_t)at;
     }
     return hipGetLastError();
 #undef RT_TRY
@@ -354,8 +367,8 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
 }  // namespace
 
 size_t LevelArena::device_bytes() const {
-    size_t total = queue_f[0].bytes + queue_f[1].bytes + counts.bytes + offsets.bytes + index.bytes + scan_temp.bytes;
-    for (int k = 0; k < LEVELS_MAX; ++k) total += ray_of_slot[k].bytes + terms[k].bytes + links[k].bytes;
+    size_t total = queue_f[0].bytes + queue_f[1].bytes + counts.bytes + offsets.bytes + scan_temp.bytes;
+    for (int k = 0; k < LEVELS_MAX; ++k) total += index[k].bytes + ray_of_slot[k].bytes + terms[k].bytes + links[k].bytes;
     return total;
 }
 
@@ -365,11 +378,13 @@ void level_arena_release(LevelArena &A) {
         b = ArenaBuffer();
     };
     for (int k = 0; k < 2; ++k) drop(A.queue_f[k]);
-    drop(A.counts), drop(A.offsets), drop(A.index), drop(A.scan_temp);
-    for (int k = 0; k < LEVELS_MAX; ++k) drop(A.ray_of_slot[k]), drop(A.terms[k]), drop(A.links[k]);
+    drop(A.counts), drop(A.offsets), drop(A.scan_temp);
+    for (int k = 0; k < LEVELS_MAX; ++k) drop(A.index[k]), drop(A.ray_of_slot[k]), drop(A.terms[k]), drop(A.links[k]);
     if (A.host_totals) (void)hipHostFree(A.host_totals);
     A.host_totals = nullptr;
     A.levels = 0;
+    A.n_known = 0;
+    A.numbered = -1;
 }
 
 // Frames of more pixels than this are rendered in chunks of rows, one after the other through the same arena: the

@@ -183,6 +183,10 @@ def test_repeated_views_are_launched_from_remembered_counts(gpu, rt, orc, levels
         for _ in range(3):  # first pass fills the memory, later passes use it (and evict and refill part of it)
             for (cam, kw), ref in zip(views, want):
                 assert np.array_equal(frame(cam, kw), ref), kw
+        # the same view several times in a row: from the second frame on, the numbering of its rays is reused as well
+        for k in (1, 0, 3):
+            for _ in range(3):
+                assert np.array_equal(frame(*views[k]), want[k]), k
         bands = np.zeros((96, 160, 3))
         for _ in range(2):
             for r in range(3):

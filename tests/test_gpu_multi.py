@@ -87,6 +87,8 @@ def test_several_workers_at_the_benchmark_frame_size(gpu, rt, orc, name):
     cam, world = sf.build_camera(w, h), sf.build_world()
     scene = world.scene()
     full, st_full = scene.render(cam, stats=True)
+    plain, _ = scene.render(cam)
+    assert np.abs(plain - full).max() <= 1e-13
     q_full = orc.quantize(full)
     buf = ctypes.c_void_p()
     assert hip.hipMalloc(ctypes.byref(buf), full.nbytes + 64) == 0
@@ -107,8 +109,10 @@ def test_several_workers_at_the_benchmark_frame_size(gpu, rt, orc, name):
                 assert info["n_units"] == 1
             multi.render_device(cam, buf.value, band_rows=band_rows, quantized=True, units=units)
             assert np.array_equal(_device_frame(hip, buf, w * h * 3, np.uint8, (h, w, 3)), q_full)
+            # (without statistics a world with groups is rendered level by level: the same pixels to within the order
+            # of a sum, so the frame to compare with is the single handle's frame rendered the same way)
             host, st = multi.render(cam, band_rows=band_rows, units=units)
-            assert np.array_equal(host, full)
+            assert np.array_equal(host, plain)
             del host
             multi.close()
     finally:

@@ -44,8 +44,8 @@ def counters_equal(stats, counters):
 
 
 def by_levels(scene):
-    """The world is rendered level by level of its ray trees (rt_scene_info.kernel_build 3: large hierarchies, or
-    RT_RENDER_LEVELS=1 when the scene was created) instead of by one launch."""
+    """The world is rendered level by level of its ray trees (rt_scene_info.kernel_build 3: worlds with groups, unless
+    RT_RENDER_LEVELS=0 when the scene was created) instead of by one launch."""
     return scene.info().kernel_build == 3
 
 
@@ -1174,11 +1174,10 @@ def test_full_4k_frame(gpu, rt, orc):
 
 
 def test_which_build_of_the_render_kernel_serves_which_world(gpu, rt, monkeypatch):
-    """rt_scene_info.kernel_build: a table of leaves for the book's flat scenes, the build without cone directions for
-    chapter_14 (groups, spheres and cylinders), the general one for hierarchies with cones under their range-skip
-    nodes, and level-by-level rendering for the generated hierarchy of 10 001 leaves.  RT_RENDER_LEVELS in the
-    environment, read when a scene is created, overrides the choice between single launch and levels for worlds with
-    groups."""
+    """rt_scene_info.kernel_build: 0 = a table of leaves for the book's flat scenes; every world with groups is rendered
+    level by level of its ray trees (3) unless RT_RENDER_LEVELS=0, read when a scene is created, asks for the single
+    launch: then the build without cone directions for chapter_14 (groups, spheres and cylinders: 2) and the general one
+    for hierarchies with cones under their range-skip nodes (1)."""
     from raytracer_rs_amd import synthetic
 
     def build(world):
@@ -1189,7 +1188,7 @@ def test_which_build_of_the_render_kernel_serves_which_world(gpu, rt, monkeypatc
     ch11 = rt.SceneFile.from_file(scene_path("chapter_11")).build_world()
     ch14 = rt.SceneFile.from_file(scene_path("chapter_14")).build_world()
     large = rt.SceneFile.from_str(synthetic.large_scene(64, 36)).build_world()
-    assert (build(ch11), build(ch14), build(large)) == (0, 2, 3)
+    assert (build(ch11), build(ch14), build(large)) == (0, 3, 3)
     monkeypatch.setenv("RT_RENDER_LEVELS", "0")
     assert (build(ch11), build(ch14), build(large)) == (0, 2, 1)
     monkeypatch.setenv("RT_RENDER_LEVELS", "1")
