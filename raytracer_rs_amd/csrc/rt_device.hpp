@@ -48,12 +48,13 @@ struct ArenaBuffer {
 constexpr int LEVELS_MAX = RT_MAX_DEPTH + 1;  // level 0 = the rays through the pixels, level k = their k-th generation of children
 struct LevelArena {
     ArenaBuffer queue_f[2];                // the rays a level reads and the rays it writes: 64 bytes each (origin, direction, weight, remaining budget)
-    ArenaBuffer counts, offsets;           // children per bin and wave of the level being rendered, and the same scanned
+    ArenaBuffer counts, offsets;           // children per kind and wave of the level being rendered, and the same scanned
     ArenaBuffer index[LEVELS_MAX];         // per level: ray number in the next level -> its slot in the queue
     ArenaBuffer ray_of_slot[LEVELS_MAX];   // the other way round, per level (kept for the sums: where a ray's children are)
     ArenaBuffer terms[LEVELS_MAX];         // per ray of a level: its term of its pixel's sum, then the sum over its subtree
     ArenaBuffer links[LEVELS_MAX];         // per ray of a level: which of its wave's children are its own
     ArenaBuffer scan_temp;
+    ArenaBuffer key_of_slot, sort_buf[3];   // sorting a level's rays: key per queue slot; keys in, keys out, slots out
     uint32_t *host_totals = nullptr;        // pinned: the level's child totals as the host reads them
     uint32_t levels = 0;                    // of the last frame: levels rendered, rays per level
     uint32_t level_rays[LEVELS_MAX] = {};
@@ -79,6 +80,7 @@ struct LevelArena {
     // rays is the same in every frame, so a frame of the view rendered last skips the counting, the scans and the
     // numbering kernels altogether.
     int32_t numbered = -1;
+    bool numbered_sorted = true;            // ... and whether that numbering is the sorted one (RT_LEVELS_SORT)
     size_t device_bytes() const;
 };
 void level_arena_release(LevelArena &arena);

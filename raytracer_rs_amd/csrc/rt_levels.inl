@@ -11,12 +11,17 @@
 //                both directions): ray through the pixel, closest hit, shading, shadow ray;
 //   level k > 0  one wave per 64 consecutive rays of the queue the level before wrote.
 //
-// A wave writes the reflection and refraction rays it spawns into slots of its own (64 per kind), counts them per
-// BIN -- the kind, and for large hierarchies kind x octant of the ray's direction -- and an exclusive scan of the
-// counts numbers the next level's rays: bin after bin, each bin in the order of the parent waves -- screen order,
-// roughly, at every level -- so a wave's 64 rays are of one kind, come from neighbouring pixels and (with octant bins)
-// travel in one octant: the node tables are ordered front to back per octant.  (Appending in the order in which waves happen to finish mixes rays from all over
-// the frame: measured, the deeper levels then take three to four times as long.)
+// A wave writes the reflection and refraction rays it spawns into slots of its own (64 per kind) and counts them per
+// kind; an exclusive scan of the counts numbers the next level's rays kind after kind, each kind in the order of the
+// parent waves, and a stable sort then groups them by (kind, octant of the direction, leaf the ray leaves): a wave's 64
+// rays are of one kind, start on one object, travel in one octant (the node tables are ordered front to back per
+// octant) and, within that, come from neighbouring pixels.  What each step bought, 8K frame of the generated 10 001-leaf
+// scene / 4K frame of chapter_14: rays appended in the order in which waves happen to finish (the textbook wavefront
+// queue) 3-4x slower at the deeper levels; parent-wave order 63 ms / 4.5 ms; octant bins 52.7 ms / 5.4 ms (chapter_14's
+// small mirror balls scatter rays, octants alone cost it screen locality); sorted by octant and leaf 47.9 ms / 3.6 ms.
+// Keys with a few bits of direction below the leaf: chapter_14 -1.5 %, generated scene +0.5 %; direction above the leaf:
+// +10 % / +5 %.  The numbering is a property of the view (scene, camera, rows, budget), not of the frame: a view
+// rendered twice in a row reuses it, and its frames launch nothing but the level kernels and the sums.
 //
 // Sums.  Each ray stores its term of its pixel's colour (path weight x surface colour, as in radiance()) under its own
 // number and remembers which of its wave's children are its own; when the last level is done, one pass per level,
@@ -28,21 +33,10 @@
 #ifndef RT_LEVEL_WAVES
 #define RT_LEVEL_WAVES 5
 #endif
-// Direction bins per kind (DIRS): the octant of the direction (8) for hierarchies of LEVELS_OCTANT_MIN_LEAVES leaves and
-// more, none (1: kinds only, screen order) for smaller ones.  Measured at 3840x2160, single launch / levels with one
-// bin / with eight, ms: generated hierarchies of 101 leaves 1.69 / 1.41 / 1.58, 401 leaves 5.27 / 3.48 / 3.38, 901
-// leaves 7.9 / 5.35 / 5.05, 1 601 leaves 8.9 / 8.55 / 8.1, 2 501 leaves 16.7 / 15.3 / 13.7, 4 901 leaves 21.2 / 18.8 /
-// 16.1, 10 001 leaves 26.3 / 22.7 / 18.3; chapter_14 (327 leaves) 4.45 / 4.40 / 5.37 -- small mirror balls scatter its
-// rays, and only screen locality keeps a wave's rays together.  Octant x longest axis (24 bins) was measured too:
-// 64.2 ms against 57.2 on the 10 001-leaf scene at 8K: finer bins take a wave's 64 rays from a larger part of the screen.
-constexpr int LEVELS_OCTANT_MIN_LEAVES = 2048;
-
 namespace {
 
 constexpr unsigned NO_CHILD = 0xffu;
 
-// (Bins of a level's children, wherever DIRS appears below: kind -- reflection 0, refraction 1 -- x direction bin; DIRS = 8:
-// the octant, bit a set: towards -a, as in DeviceScene::oct_tables; DIRS = 1: no direction bins.)
 struct LevelIO {
     // the rays of this level (unused at level 0)
     const double *in_f = nullptr;       // eight doubles per slot, one 64-byte line: origin, direction, weight, remaining budget
@@ -50,8 +44,10 @@ struct LevelIO {
     uint32_t n_rays = 0;
     // what it writes
     double *out_f = nullptr;            // 128 slots per wave: kind * 64 * waves + wave * 64 + k
-    uint32_t *out_counts = nullptr;     // [2 * DIRS][waves + 1]: children per bin (kind * DIRS + direction bin) and wave;
+    uint32_t *out_counts = nullptr;     // [2][waves + 1]: children per kind (reflection 0, refraction 1) and wave;
                                         // nullptr: not wanted (the numbering of this view's rays is in place already)
+    uint32_t *out_keys = nullptr;       // per slot of out_f: what the next level's rays are sorted by (nullptr: not wanted)
+    uint32_t leaf_bits = 0;             // of a key: (kind * 8 + direction octant) << leaf_bits | leaf
     uint32_t waves = 0;
     double *terms = nullptr;            // three doubles per ray
     uint8_t *links = nullptr;           // two arrays of 64 * waves bytes: k of the ray's reflection / refraction, or NO_CHILD
@@ -67,7 +63,7 @@ __device__ __forceinline__ bool level0_tile(unsigned wave, unsigned blocks_x, un
     return tx < tiles_x && ty < tiles_y;
 }
 
-template <int NEST, bool TIES, bool FIRST, unsigned DIRS>
+template <int NEST, bool TIES, bool FIRST>
 __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth, LevelIO io) {
     const unsigned lane = threadIdx.x & 63;
     const unsigned wave = blockIdx.x;
@@ -101,30 +97,27 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
     }
     if (FIRST && __ballot(have) == 0ull) {  // a tile outside the frame (the launch is padded to whole blocks of tiles)
         const size_t n = (size_t)io.waves * 64, i = (size_t)wave * 64 + lane;
-        if (io.out_counts && lane < 2u * DIRS) io.out_counts[lane * (io.waves + 1u) + wave] = 0u;
+        if (io.out_counts && lane < 2u) io.out_counts[lane * (io.waves + 1u) + wave] = 0u;
         io.terms[3 * i] = 0.0, io.terms[3 * i + 1] = 0.0, io.terms[3 * i + 2] = 0.0;
         io.links[i] = (uint8_t)NO_CHILD, io.links[n + i] = (uint8_t)NO_CHILD;
         return;
     }
-    // The wave's children of one kind, packed into its 64 slots for that kind, octant after octant; returns the lane's k
-    // (NO_CHILD if none).
-    auto append = [&](bool want, unsigned kind, V3 o, V3 d, double pw, int prem) -> unsigned {
-        unsigned oct = (d.x < 0.0 ? 1u : 0u) | (d.y < 0.0 ? 2u : 0u) | (d.z < 0.0 ? 4u : 0u);
-        if constexpr (DIRS == 1) oct = 0u;
-        unsigned k = 0, before = 0;
-#pragma unroll
-        for (unsigned b = 0; b < DIRS; ++b) {
-            const unsigned long long m = __ballot(want && oct == b);
-            const unsigned n = (unsigned)__popcll(m);
-            if (io.out_counts && lane == b) io.out_counts[(kind * DIRS + b) * (io.waves + 1u) + wave] = n;
-            if (oct == b) k = before + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            before += n;
-        }
+    // The wave's children of one kind, packed into its 64 slots for that kind; returns the lane's k (NO_CHILD if none).
+    // `leaf`: the object the ray leaves.
+    auto append = [&](bool want, unsigned kind, V3 o, V3 d, double pw, int prem, int leaf) -> unsigned {
+        const unsigned long long m = __ballot(want);
+        if (io.out_counts && lane == 0u) io.out_counts[kind * (io.waves + 1u) + wave] = (unsigned)__popcll(m);
         if (!want) return NO_CHILD;
+        const unsigned k = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         const size_t slot = (size_t)kind * 64 * io.waves + (size_t)wave * 64 + k;
         double4 *f = reinterpret_cast<double4 *>(io.out_f + slot * 8);
         f[0] = make_double4(o.x, o.y, o.z, d.x);
         f[1] = make_double4(d.y, d.z, pw, __hiloint2double(0, prem));
+        if (io.out_keys) {
+            // (bit a of the octant set: towards -a, as in DeviceScene::oct_tables)
+            const unsigned oct = (d.x < 0.0 ? 1u : 0u) | (d.y < 0.0 ? 2u : 0u) | (d.z < 0.0 ? 4u : 0u);
+            io.out_keys[slot] = ((kind * 8u + oct) << io.leaf_bits) | (unsigned)leaf;
+        }
         return k;
     };
 
@@ -141,8 +134,8 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
         term_lit = h.lit * w;
         term = h.shadowed * w;
     }
-    const unsigned k_reflect = append(shade && h.reflect, 0u, h.over, reflect(rd, h.normal), h.w_reflect, remaining - 1);
-    const unsigned k_refract = append(shade && h.refract, 1u, h.under, h.refract_dir, h.w_refract, remaining - 1);
+    const unsigned k_reflect = append(shade && h.reflect, 0u, h.over, reflect(rd, h.normal), h.w_reflect, remaining - 1, best.leaf);
+    const unsigned k_refract = append(shade && h.refract, 1u, h.under, h.refract_dir, h.w_refract, remaining - 1, best.leaf);
     if (__ballot(shade) != 0ull) {
         const bool in_shadow = occluded<NEST, false>(S, h.over, h.shadow_dir, shade, h.light_distance, ctr);  // world.rs:145-148
         if (shade && !in_shadow) term = term_lit;
@@ -155,30 +148,39 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
     io.links[n + i] = (uint8_t)k_refract;
 }
 
-// Numbers the children of one level: child k of kind `kind` of parent wave p lies in slot kind * 64 * waves + p * 64 + k;
-// its bin is the one whose run of p's block holds k, and its number in the next level is the scanned count of (bin, p)
-// plus its place in that run.  Writes both directions of the mapping.  One wave per (parent, kind), a lane per slot:
-// the counts are wave-uniform reads (scalar loads) and the writes to ray_of_slot contiguous; four waves to a
-// workgroup.  2 ms of an 8K frame of the generated scene.  (Measured and slower: the same without telling the compiler
-// that a wave's unit is uniform -- the counts then come through vector loads, +1.5 ms -- and one thread per (parent, bin)
-// writing its run serially, +3 ms.)
+// Numbers the children of one level: child k of kind `kind` of parent wave p lies in slot kind * 64 * waves + p * 64 + k,
+// and its number in the next level is the scanned count of (kind, p) plus k.  Writes both directions of the mapping.
+// One wave per (parent, kind), a lane per slot: the counts are wave-uniform reads (scalar loads) and the writes
+// contiguous; four waves to a workgroup.
 __global__ __launch_bounds__(256) void level_index_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets, uint32_t waves,
-                                                          uint32_t dirs, uint32_t *__restrict__ slot_of_ray, uint32_t *__restrict__ ray_of_slot) {
+                                                          uint32_t *__restrict__ slot_of_ray, uint32_t *__restrict__ ray_of_slot) {
     // (readfirstlane: the unit is the same for a wave's 64 lanes, and saying so keeps the counts in scalar loads)
     const unsigned unit = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));  // (parent, kind)
     if (unit >= 2u * waves) return;
     const unsigned kind = unit >= waves ? 1u : 0u, p = unit - kind * waves, k = threadIdx.x & 63u;
-    unsigned before = 0;
-    for (unsigned b = 0; b < dirs; ++b) {
-        const size_t at = (size_t)(kind * dirs + b) * (waves + 1u) + p;
-        const unsigned n = counts[at];
-        if (k >= before && k < before + n) {
-            const size_t slot = (size_t)kind * 64 * waves + (size_t)p * 64 + k;
-            const uint32_t ray = offsets[at] + (k - before);
-            slot_of_ray[ray] = (uint32_t)slot;
-            ray_of_slot[slot] = ray;
-        }
-        before += n;
+    const size_t at = (size_t)kind * (waves + 1u) + p;
+    if (k < counts[at]) {
+        const size_t slot = (size_t)kind * 64 * waves + (size_t)p * 64 + k;
+        const uint32_t ray = offsets[at] + k;
+        slot_of_ray[ray] = (uint32_t)slot;
+        ray_of_slot[slot] = ray;
+    }
+}
+
+// Sorting a level's rays: the key of every ray in the order of the numbering, and after the (stable) sort both
+// directions of the mapping again.
+__global__ __launch_bounds__(256) void level_key_gather_kernel(const uint32_t *__restrict__ slot_of_ray, const uint32_t *__restrict__ key_of_slot, uint32_t n,
+                                                               uint32_t *__restrict__ keys) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = key_of_slot[slot_of_ray[i]];
+}
+__global__ __launch_bounds__(256) void level_renumber_kernel(const uint32_t *__restrict__ sorted_slots, uint32_t n, uint32_t *__restrict__ slot_of_ray,
+                                                             uint32_t *__restrict__ ray_of_slot) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t slot = sorted_slots[i];
+        slot_of_ray[i] = slot;
+        ray_of_slot[slot] = (uint32_t)i;
     }
 }
 
@@ -239,7 +241,7 @@ hipError_t reserve(ArenaBuffer &b, size_t bytes, bool frozen) {
     return hipSuccess;
 }
 
-template <int NEST, bool TIES, unsigned DIRS>
+template <int NEST, bool TIES>
 hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, const RowMap &rows, int max_depth, double *rgb, LevelArena &A,
                          hipStream_t stream) {
 #define RT_TRY(expr)                       \
@@ -255,6 +257,11 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         if (A.frozen) return hipErrorNotReady;
         RT_TRY(hipHostMalloc((void **)&A.host_totals, 2 * sizeof(uint32_t), 0));
     }
+    const char *sort_env = getenv("RT_LEVELS_SORT");  // =0: rays stay in the order of their parent waves (tests compare the two)
+    const bool sorted = !(sort_env && sort_env[0] == '0');
+    uint32_t leaf_bits = 1;
+    while (leaf_bits < 28 && (1u << leaf_bits) < (uint32_t)scene.n_leaves) ++leaf_bits;
+    if ((uint32_t)scene.n_leaves > (1u << 28)) return hipErrorInvalidValue;
     // Seen this view before?  Then every level's ray count is known and nothing below waits for the GPU.
     LevelArena::Known *known = nullptr;
     const uint32_t view[5] = {rows.row_begin, rows.row_end, rows.n_rows, rows.band_rows, rows.band_pitch};
@@ -268,7 +275,12 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         }
     if (A.frozen && !known) return hipErrorNotReady;  // (learning a view's ray counts means waiting for the GPU)
     // The view rendered last?  Then its rays' numbering is still in the arena, and it is the same in every frame.
-    const bool numbered = known && A.numbered == (int32_t)(known - A.known);
+    // (Not while the stream is being captured: a graph must hold the numbering kernels too, or replaying it after another
+    // view was rendered through this handle would read that view's numbering.)
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (stream) RT_TRY(hipStreamIsCapturing(stream, &capture));
+    const bool capturing = capture != hipStreamCaptureStatusNone;
+    const bool numbered = !capturing && known && A.numbered == (int32_t)(known - A.known) && A.numbered_sorted == sorted;
     if (!numbered) A.numbered = -1;  // (about to be overwritten)
     const size_t lds = lds_bytes<NEST, false>(64);
     unsigned waves = blocks_x * blocks_y * 64, n_rays = waves * 64, levels = 0;
@@ -278,13 +290,14 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         const bool last = level == max_depth;  // its rays have no budget left: nothing is appended
         RT_TRY(reserve(A.terms[level], (size_t)waves * 64 * 3 * sizeof(double), A.frozen));
         RT_TRY(reserve(A.links[level], (size_t)waves * 64 * 2, A.frozen));
-        const size_t table = ((size_t)waves + 1) * 2 * DIRS;  // per bin: one count per wave and a last entry that stays zero
+        const size_t table = ((size_t)waves + 1) * 2;  // per kind: one count per wave and a last entry that stays zero
         if (table > 0x7fffffffull) return hipErrorInvalidValue;  // (the scan counts its items in an int)
         RT_TRY(reserve(A.counts, table * sizeof(uint32_t), A.frozen));
         if (!last) {
             RT_TRY(reserve(A.queue_f[out], (size_t)waves * 128 * 8 * sizeof(double), A.frozen));
             RT_TRY(reserve(A.offsets, table * sizeof(uint32_t), A.frozen));
             RT_TRY(reserve(A.ray_of_slot[level], (size_t)waves * 128 * sizeof(uint32_t), A.frozen));
+            if (sorted && !numbered) RT_TRY(reserve(A.key_of_slot, (size_t)waves * 128 * sizeof(uint32_t), A.frozen));
         }
         LevelIO io;
         io.in_f = (const double *)A.queue_f[in].p;
@@ -292,6 +305,8 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         io.n_rays = n_rays;
         io.out_f = (double *)A.queue_f[out].p;
         io.out_counts = numbered ? nullptr : (uint32_t *)A.counts.p;
+        io.out_keys = sorted && !numbered && !last ? (uint32_t *)A.key_of_slot.p : nullptr;
+        io.leaf_bits = leaf_bits;
         io.waves = waves;
         io.terms = (double *)A.terms[level].p;
         io.links = (uint8_t *)A.links[level].p;
@@ -301,8 +316,8 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         levels = level + 1;
         uint32_t *counts = (uint32_t *)A.counts.p, *offsets = (uint32_t *)A.offsets.p;
         if (!last && !numbered) RT_TRY(hipMemsetAsync(counts, 0, table * sizeof(uint32_t), stream));  // (the last entry of every bin must read as zero)
-        if (level == 0) level_kernel<NEST, TIES, true, DIRS><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
-        else level_kernel<NEST, TIES, false, DIRS><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
+        if (level == 0) level_kernel<NEST, TIES, true><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
+        else level_kernel<NEST, TIES, false><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
         RT_TRY(hipGetLastError());
         if (last) break;
         if (numbered) {
@@ -311,7 +326,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
             waves = (n_rays + 63) / 64;
             continue;
         }
-        // number the children: bin after bin, each bin in the order of the parent waves
+        // number the children: kind after kind, each kind in the order of the parent waves
         size_t need = 0;
         RT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, counts, offsets, (int)table, stream));
         RT_TRY(reserve(A.scan_temp, need, A.frozen));
@@ -328,8 +343,21 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         if (children == 0) break;
         if (children > 0x3fffffffull) return hipErrorOutOfMemory;
         RT_TRY(reserve(A.index[level], (size_t)children * sizeof(uint32_t), A.frozen));
-        level_index_kernel<<<dim3((2 * waves + 3) / 4), 256, 0, stream>>>(counts, offsets, waves, DIRS, (uint32_t *)A.index[level].p,
+        level_index_kernel<<<dim3((2 * waves + 3) / 4), 256, 0, stream>>>(counts, offsets, waves, (uint32_t *)A.index[level].p,
                                                                           (uint32_t *)A.ray_of_slot[level].p);
+        if (sorted) {  // ... then group them by (kind, octant, leaf), keeping that order within a group
+            const unsigned n = (unsigned)children;
+            for (int k = 0; k < 3; ++k) RT_TRY(reserve(A.sort_buf[k], (size_t)n * sizeof(uint32_t), A.frozen));
+            uint32_t *keys_in = (uint32_t *)A.sort_buf[0].p, *keys_out = (uint32_t *)A.sort_buf[1].p, *vals_out = (uint32_t *)A.sort_buf[2].p;
+            uint32_t *slot_of_ray = (uint32_t *)A.index[level].p;
+            level_key_gather_kernel<<<dim3((n + 255) / 256), 256, 0, stream>>>(slot_of_ray, (const uint32_t *)A.key_of_slot.p, n, keys_in);
+            size_t sort_need = 0;
+            RT_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_need, keys_in, keys_out, slot_of_ray, vals_out, (int)n, 0, (int)leaf_bits + 4, stream));
+            RT_TRY(reserve(A.scan_temp, sort_need, A.frozen));
+            size_t sort_bytes = A.scan_temp.bytes;
+            RT_TRY(hipcub::DeviceRadixSort::SortPairs(A.scan_temp.p, sort_bytes, keys_in, keys_out, slot_of_ray, vals_out, (int)n, 0, (int)leaf_bits + 4, stream));
+            level_renumber_kernel<<<dim3((n + 255) / 256), 256, 0, stream>>>(vals_out, n, slot_of_ray, (uint32_t *)A.ray_of_slot[level].p);
+        }
         n_rays = (unsigned)children;
         waves = (n_rays + 63) / 64;
     }
@@ -341,7 +369,8 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
     }
     level_store_kernel<<<dim3(level_waves[0]), 64, 0, stream>>>(camera, rows, (const double *)A.terms[0].p, level_waves[0], blocks_x, rgb);
     A.levels = levels;
-    if (known) A.numbered = (int32_t)(known - A.known);
+    A.numbered_sorted = sorted;
+    if (known) A.numbered = capturing ? -1 : (int32_t)(known - A.known);
     if (!known && remember) {  // remember this view's counts (in place of the entry unused for longest when all are taken)
         uint32_t at = A.n_known;
         if (at == LevelArena::KNOWN_MAX) {
@@ -367,7 +396,8 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
 }  // namespace
 
 size_t LevelArena::device_bytes() const {
-    size_t total = queue_f[0].bytes + queue_f[1].bytes + counts.bytes + offsets.bytes + scan_temp.bytes;
+    size_t total = queue_f[0].bytes + queue_f[1].bytes + counts.bytes + offsets.bytes + scan_temp.bytes + key_of_slot.bytes + sort_buf[0].bytes + sort_buf[1].bytes +
+                   sort_buf[2].bytes;
     for (int k = 0; k < LEVELS_MAX; ++k) total += index[k].bytes + ray_of_slot[k].bytes + terms[k].bytes + links[k].bytes;
     return total;
 }
@@ -378,7 +408,8 @@ void level_arena_release(LevelArena &A) {
         b = ArenaBuffer();
     };
     for (int k = 0; k < 2; ++k) drop(A.queue_f[k]);
-    drop(A.counts), drop(A.offsets), drop(A.scan_temp);
+    drop(A.counts), drop(A.offsets), drop(A.scan_temp), drop(A.key_of_slot);
+    for (int k = 0; k < 3; ++k) drop(A.sort_buf[k]);
     for (int k = 0; k < LEVELS_MAX; ++k) drop(A.index[k]), drop(A.ray_of_slot[k]), drop(A.terms[k]), drop(A.links[k]);
     if (A.host_totals) (void)hipHostFree(A.host_totals);
     A.host_totals = nullptr;
@@ -432,15 +463,8 @@ hipError_t launch_render_levels(const DeviceScene &scene, const RtCameraDev &cam
         }
         rows.n_tiles = ((camera.hsize + 7) / 8) * ((rows.n_rows + 7) / 8);
         rows.tile_list = nullptr;
-        // (a property of the scene: the same for every launch; RT_LEVELS_OCTANT_MIN_LEAVES in the environment moves the
-        // threshold, so that tests can put small worlds of every kind through the octant bins)
-        int octant_min = LEVELS_OCTANT_MIN_LEAVES;
-        if (const char *env = getenv("RT_LEVELS_OCTANT_MIN_LEAVES")) octant_min = atoi(env);
-        const bool octants = scene.n_leaves >= octant_min;
         const int build = scene.any_order != 0 && scene.cone_nodes == 0 ? 2 : scene.any_order != 0 ? 1 : 0;
-#define RT_LEVELS(N, T)                                                                                          \
-    (octants ? render_levels<N, T, 8>(scene, camera, rows, max_depth, out, arena, stream)                        \
-             : render_levels<N, T, 1>(scene, camera, rows, max_depth, out, arena, stream))
+#define RT_LEVELS(N, T) render_levels<N, T>(scene, camera, rows, max_depth, out, arena, stream)
         e = build == 2 ? RT_LEVELS(2, true) : build == 1 ? RT_LEVELS(1, true) : RT_LEVELS(1, false);
 #undef RT_LEVELS
     }

@@ -33,11 +33,11 @@ def _fetch(hip, ptr, shape, dtype):
     return out
 
 
-@pytest.mark.parametrize("octants", [False, True])
+@pytest.mark.parametrize("sort", [True, False])
 @pytest.mark.parametrize("scene", ["chapter_12", "chapter_14"])
-def test_book_scenes_with_groups_level_by_level(gpu, rt, orc, levels, monkeypatch, scene, octants):
-    if octants:
-        monkeypatch.setenv("RT_LEVELS_OCTANT_MIN_LEAVES", "0")  # rays binned by direction octant too, as in large hierarchies
+def test_book_scenes_with_groups_level_by_level(gpu, rt, orc, levels, monkeypatch, scene, sort):
+    if not sort:
+        monkeypatch.setenv("RT_LEVELS_SORT", "0")  # a level's rays left in the order of their parent waves
     cam, world, ocam, oworld = load_both(rt, orc, scene)
     s = world.scene()
     assert s.info().kernel_build == 3
@@ -52,18 +52,18 @@ def test_book_scenes_with_groups_level_by_level(gpu, rt, orc, levels, monkeypatc
     assert np.array_equal(again, plain), "two renders of the same frame differ"
 
 
-@pytest.mark.parametrize("octants", [False, True])
+@pytest.mark.parametrize("sort", [True, False])
 @pytest.mark.parametrize("seed,n_top", [(1, 6), (4, 6), (9, 6), (12, 6), (101, 25), (103, 60), (104, 90)])
-def test_random_worlds_level_by_level(gpu, rt, orc, levels, monkeypatch, seed, n_top, octants):
+def test_random_worlds_level_by_level(gpu, rt, orc, levels, monkeypatch, seed, n_top, sort):
     """Random hierarchies (every shape, cones under range-skip nodes, nested groups, patterns, glass and mirrors), with
-    the next level's rays binned by kind alone (what worlds of this size get) and by kind and direction octant (what
-    large hierarchies get; RT_LEVELS_OCTANT_MIN_LEAVES=0 hands it to every world)."""
+    every level's rays sorted by kind, direction octant and the leaf they leave (the default) and left in the order of
+    their parent waves (RT_LEVELS_SORT=0, read per call)."""
     import tomli
 
     from raytracer_rs_amd import synthetic
 
-    if octants:
-        monkeypatch.setenv("RT_LEVELS_OCTANT_MIN_LEAVES", "0")
+    if not sort:
+        monkeypatch.setenv("RT_LEVELS_SORT", "0")
     text = synthetic.random_scene(seed, 96, 64, n_top)
     sf = rt.SceneFile.from_str(text)
     cam, world = sf.build_camera(), sf.build_world()
@@ -187,6 +187,14 @@ def test_repeated_views_are_launched_from_remembered_counts(gpu, rt, orc, levels
         for k in (1, 0, 3):
             for _ in range(3):
                 assert np.array_equal(frame(*views[k]), want[k]), k
+        # the order of a level's rays is no part of the result: frames with the rays left unsorted, of views numbered
+        # sorted before, and back
+        monkeypatch.setenv("RT_LEVELS_SORT", "0")
+        for k in (0, 0, 1):
+            assert np.array_equal(frame(*views[k]), want[k]), k
+        monkeypatch.delenv("RT_LEVELS_SORT")
+        for k in (1, 1, 0):
+            assert np.array_equal(frame(*views[k]), want[k]), k
         bands = np.zeros((96, 160, 3))
         for _ in range(2):
             for r in range(3):
