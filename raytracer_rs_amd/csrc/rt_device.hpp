@@ -79,6 +79,8 @@ struct LevelArena {
     // Which remembered view the numbering in index[] / ray_of_slot[] belongs to (-1: none).  The numbering of a view's
     // rays is the same in every frame, so a frame of the view rendered last skips the counting, the scans and the
     // numbering kernels altogether.
+    ArenaBuffer wave_cost, wave_order[LEVELS_MAX];  // shader clocks per wave of the level just rendered; per level: the waves in launch order
+    bool ordered = false;                   // wave_order[] belongs to the numbering in place
     int32_t numbered = -1;
     bool numbered_sorted = true;            // ... and whether that numbering is the sorted one (RT_LEVELS_SORT)
     size_t device_bytes() const;

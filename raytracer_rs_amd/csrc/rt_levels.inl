@@ -28,6 +28,11 @@
 // deepest first, adds to every ray the sums of its two children -- reflection, then refraction: the order of
 // world.rs:107-110.  A pixel's colour is therefore a function of its own ray tree alone: it does not depend on the
 // launch, the rows rendered with it, or the order in which waves run.
+//
+// Launch order.  A view's first frame also records what every wave of every level cost (shader clocks); later frames
+// of the view launch a level's waves by the quarter-octave of that cost, most expensive first and otherwise in their own
+// order, as render_kernel launches its tiles by estimated cost: the under-occupied end of every launch shrinks (4K
+// chapter_14 3.63 -> 3.41 ms, generated scene at 1080p 6.2 -> 4.7 ms, at 8K 48.2 -> 46.9 ms).
 // Five waves per SIMD (96 VGPRs, ten to twenty of the traversal's values spilled).  The generated scene at 8K: 55.9 ms
 // at five, 57.2 at six, 67.4 at seven (and, before rays were binned by octant, 63.8 / 62.7 at five / six, 68.9 at four).
 #ifndef RT_LEVEL_WAVES
@@ -48,6 +53,8 @@ struct LevelIO {
                                         // nullptr: not wanted (the numbering of this view's rays is in place already)
     uint32_t *out_keys = nullptr;       // per slot of out_f: what the next level's rays are sorted by (nullptr: not wanted)
     uint32_t leaf_bits = 0;             // of a key: (kind * 8 + direction octant) << leaf_bits | leaf
+    uint32_t *out_cost = nullptr;       // per wave: the shader clocks it took (nullptr: not wanted)
+    const uint32_t *wave_order = nullptr; // which wave's rays the k-th workgroup takes (nullptr: its own)
     uint32_t waves = 0;
     double *terms = nullptr;            // three doubles per ray
     uint8_t *links = nullptr;           // two arrays of 64 * waves bytes: k of the ray's reflection / refraction, or NO_CHILD
@@ -66,7 +73,8 @@ __device__ __forceinline__ bool level0_tile(unsigned wave, unsigned blocks_x, un
 template <int NEST, bool TIES, bool FIRST>
 __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, int max_depth, LevelIO io) {
     const unsigned lane = threadIdx.x & 63;
-    const unsigned wave = blockIdx.x;
+    const long long began = io.out_cost ? clock64() : 0ll;
+    const unsigned wave = io.wave_order ? (unsigned)__builtin_amdgcn_readfirstlane((int)io.wave_order[blockIdx.x]) : blockIdx.x;
     SceneK S = scene_k<NEST, false>(scene, max_depth);
     Ctr<false> ctr;
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
@@ -98,6 +106,7 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
     if (FIRST && __ballot(have) == 0ull) {  // a tile outside the frame (the launch is padded to whole blocks of tiles)
         const size_t n = (size_t)io.waves * 64, i = (size_t)wave * 64 + lane;
         if (io.out_counts && lane < 2u) io.out_counts[lane * (io.waves + 1u) + wave] = 0u;
+        if (io.out_cost && lane == 0u) io.out_cost[wave] = 0u;
         io.terms[3 * i] = 0.0, io.terms[3 * i + 1] = 0.0, io.terms[3 * i + 2] = 0.0;
         io.links[i] = (uint8_t)NO_CHILD, io.links[n + i] = (uint8_t)NO_CHILD;
         return;
@@ -146,6 +155,22 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
     io.terms[3 * i + 2] = term.z;
     io.links[i] = (uint8_t)k_reflect;
     io.links[n + i] = (uint8_t)k_refract;
+    if (io.out_cost && lane == 0u) {
+        const long long took = clock64() - began;
+        io.out_cost[wave] = took > 0x7fffffffll ? 0x7fffffffu : (uint32_t)took;
+    }
+}
+
+// The launch order of a level's waves: by the quarter-octave of what they cost the last time, most expensive first,
+// waves of one class in their own order.  Keys for a stable sort, and the identity to sort along.
+__global__ __launch_bounds__(256) void level_cost_key_kernel(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ keys, uint32_t *__restrict__ ids) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = cost[i] | 4u;
+    const uint32_t e = 31u - (uint32_t)__clz((int)c);
+    const uint32_t cls = (e << 2) | ((c >> (e - 2u)) & 3u);  // < 128
+    keys[i] = 127u - cls;
+    ids[i] = (uint32_t)i;
 }
 
 // Numbers the children of one level: child k of kind `kind` of parent wave p lies in slot kind * 64 * waves + p * 64 + k,
@@ -259,6 +284,8 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
     }
     const char *sort_env = getenv("RT_LEVELS_SORT");  // =0: rays stay in the order of their parent waves (tests compare the two)
     const bool sorted = !(sort_env && sort_env[0] == '0');
+    const char *order_env = getenv("RT_LEVELS_ORDER");  // =0: a level's waves are launched in the order of their rays
+    const bool ordered = !(order_env && order_env[0] == '0');
     uint32_t leaf_bits = 1;
     while (leaf_bits < 28 && (1u << leaf_bits) < (uint32_t)scene.n_leaves) ++leaf_bits;
     if ((uint32_t)scene.n_leaves > (1u << 28)) return hipErrorInvalidValue;
@@ -307,6 +334,12 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         io.out_counts = numbered ? nullptr : (uint32_t *)A.counts.p;
         io.out_keys = sorted && !numbered && !last ? (uint32_t *)A.key_of_slot.p : nullptr;
         io.leaf_bits = leaf_bits;
+        if (ordered && !numbered) {
+            RT_TRY(reserve(A.wave_cost, (size_t)waves * sizeof(uint32_t), A.frozen));
+            RT_TRY(reserve(A.wave_order[level], (size_t)waves * sizeof(uint32_t), A.frozen));
+            io.out_cost = (uint32_t *)A.wave_cost.p;
+        }
+        if (ordered && numbered && A.ordered) io.wave_order = (const uint32_t *)A.wave_order[level].p;
         io.waves = waves;
         io.terms = (double *)A.terms[level].p;
         io.links = (uint8_t *)A.links[level].p;
@@ -319,6 +352,16 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         if (level == 0) level_kernel<NEST, TIES, true><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
         else level_kernel<NEST, TIES, false><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
         RT_TRY(hipGetLastError());
+        if (ordered && !numbered) {
+            for (int k = 0; k < 3; ++k) RT_TRY(reserve(A.sort_buf[k], (size_t)waves * sizeof(uint32_t), A.frozen));
+            uint32_t *keys_in = (uint32_t *)A.sort_buf[0].p, *keys_out = (uint32_t *)A.sort_buf[1].p, *ids = (uint32_t *)A.sort_buf[2].p;
+            level_cost_key_kernel<<<dim3((waves + 255) / 256), 256, 0, stream>>>((const uint32_t *)A.wave_cost.p, waves, keys_in, ids);
+            size_t sort_need = 0;
+            RT_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_need, keys_in, keys_out, ids, (uint32_t *)A.wave_order[level].p, (int)waves, 0, 7, stream));
+            RT_TRY(reserve(A.scan_temp, sort_need, A.frozen));
+            size_t sort_bytes = A.scan_temp.bytes;
+            RT_TRY(hipcub::DeviceRadixSort::SortPairs(A.scan_temp.p, sort_bytes, keys_in, keys_out, ids, (uint32_t *)A.wave_order[level].p, (int)waves, 0, 7, stream));
+        }
         if (last) break;
         if (numbered) {
             if ((uint32_t)level + 1 >= known->levels) break;
@@ -370,6 +413,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
     level_store_kernel<<<dim3(level_waves[0]), 64, 0, stream>>>(camera, rows, (const double *)A.terms[0].p, level_waves[0], blocks_x, rgb);
     A.levels = levels;
     A.numbered_sorted = sorted;
+    if (!numbered) A.ordered = ordered;
     if (known) A.numbered = capturing ? -1 : (int32_t)(known - A.known);
     if (!known && remember) {  // remember this view's counts (in place of the entry unused for longest when all are taken)
         uint32_t at = A.n_known;
@@ -397,7 +441,8 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
 
 size_t LevelArena::device_bytes() const {
     size_t total = queue_f[0].bytes + queue_f[1].bytes + counts.bytes + offsets.bytes + scan_temp.bytes + key_of_slot.bytes + sort_buf[0].bytes + sort_buf[1].bytes +
-                   sort_buf[2].bytes;
+                   sort_buf[2].bytes + wave_cost.bytes;
+    for (int k = 0; k < LEVELS_MAX; ++k) total += wave_order[k].bytes;
     for (int k = 0; k < LEVELS_MAX; ++k) total += index[k].bytes + ray_of_slot[k].bytes + terms[k].bytes + links[k].bytes;
     return total;
 }
@@ -408,7 +453,8 @@ void level_arena_release(LevelArena &A) {
         b = ArenaBuffer();
     };
     for (int k = 0; k < 2; ++k) drop(A.queue_f[k]);
-    drop(A.counts), drop(A.offsets), drop(A.scan_temp), drop(A.key_of_slot);
+    drop(A.counts), drop(A.offsets), drop(A.scan_temp), drop(A.key_of_slot), drop(A.wave_cost);
+    for (int k = 0; k < LEVELS_MAX; ++k) drop(A.wave_order[k]);
     for (int k = 0; k < 3; ++k) drop(A.sort_buf[k]);
     for (int k = 0; k < LEVELS_MAX; ++k) drop(A.index[k]), drop(A.ray_of_slot[k]), drop(A.terms[k]), drop(A.links[k]);
     if (A.host_totals) (void)hipHostFree(A.host_totals);

@@ -195,6 +195,13 @@ def test_repeated_views_are_launched_from_remembered_counts(gpu, rt, orc, levels
         monkeypatch.delenv("RT_LEVELS_SORT")
         for k in (1, 1, 0):
             assert np.array_equal(frame(*views[k]), want[k]), k
+        # nor is the order in which a level's waves are launched (by measured cost from a view's second frame on)
+        monkeypatch.setenv("RT_LEVELS_ORDER", "0")
+        for k in (0, 0, 0, 3, 3):
+            assert np.array_equal(frame(*views[k]), want[k]), k
+        monkeypatch.delenv("RT_LEVELS_ORDER")
+        for k in (3, 3, 3, 1, 1, 1):
+            assert np.array_equal(frame(*views[k]), want[k]), k
         bands = np.zeros((96, 160, 3))
         for _ in range(2):
             for r in range(3):
