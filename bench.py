@@ -182,6 +182,16 @@ def time_config(scene, cam, stream, reps: int, quantized: bool, config: str = No
            "scene_device_mb": round(scene.info().device_bytes / 1e6, 1)}  # tables, and the ray queues of worlds rendered level by level
     if peak:
         out["frac_reference_work_of_measured_unfused"] = round(ref_tf / peak["unfused"], 4)
+    if scene.info().kernel_build == 3:
+        # ms_per_frame above is a frame of a view the handle has rendered before: the numbering of its rays (scans, a
+        # sort per level) and the launch order of its waves are remembered per view.  What a view's FIRST frame costs,
+        # waits per level included: all rows but the last eight are a view of their own whose queues exist already.
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        scene.render_device(cam, buf.data_ptr(), (0, H - 8), None, stream, False, False, quantized)
+        torch.cuda.synchronize()
+        out["new_view_frame_ms"] = round((time.perf_counter() - t0) * 1e3 * H / (H - 8), 3)
+        out["new_view_note"] = "first frame of a view (camera, rows, depth): one wait per level, numbering and sort of every level's rays, wave costs recorded; ms_per_frame is every later frame of the view"
     if config:
         pmc = committed_pmc(config)
         out["hbm_bytes"] = pmc.get("traffic")

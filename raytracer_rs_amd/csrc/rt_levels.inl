@@ -233,9 +233,11 @@ __global__ __launch_bounds__(256) void level_sum_kernel(double *__restrict__ ter
     terms[3 * i + 2] = sum.z;
 }
 
-// The finished sums of level 0 are the pixels: Canvas::write_pixel per tile, as render_kernel does it.
-__global__ __launch_bounds__(64) void level_store_kernel(RtCameraDev cam, RowMap rows, const double *__restrict__ terms, uint32_t waves, uint32_t blocks_x,
-                                                         double *__restrict__ rgb) {
+// The sums of level 0 are the pixels: a pixel's own term plus the finished sums of its two children (none when the
+// frame has a single level), then Canvas::write_pixel per tile, as render_kernel does it.
+__global__ __launch_bounds__(64) void level_store_kernel(RtCameraDev cam, RowMap rows, const double *__restrict__ terms, const uint8_t *__restrict__ links,
+                                                         const uint32_t *__restrict__ ray_of_slot, const double *__restrict__ child, uint32_t waves,
+                                                         uint32_t blocks_x, double *__restrict__ rgb) {
     __shared__ double staging[192];
     const unsigned lane = threadIdx.x & 63, wave = blockIdx.x;
     const unsigned tiles_x = (cam.hsize + 7) >> 3, tiles_y = (rows.n_rows + 7) >> 3;
@@ -246,7 +248,19 @@ __global__ __launch_bounds__(64) void level_store_kernel(RtCameraDev cam, RowMap
     const unsigned y = image_row(rows, r);
     const bool valid = x < cam.hsize && r < rows.n_rows && y < rows.row_end;
     const size_t i = (size_t)wave * 64 + lane;
-    const V3 acc = mk(terms[3 * i], terms[3 * i + 1], terms[3 * i + 2]);
+    V3 acc = mk(terms[3 * i], terms[3 * i + 1], terms[3 * i + 2]);
+    if (child) {
+        const size_t n = (size_t)waves * 64, block = (size_t)wave * 64;
+        const unsigned k0 = links[i], k1 = links[n + i];
+        if (k0 != NO_CHILD) {
+            const size_t j = 3 * (size_t)ray_of_slot[block + k0];
+            acc = acc + mk(child[j], child[j + 1], child[j + 2]);
+        }
+        if (k1 != NO_CHILD) {
+            const size_t j = 3 * (size_t)ray_of_slot[n + block + k1];
+            acc = acc + mk(child[j], child[j + 1], child[j + 2]);
+        }
+    }
     store_tile(cam, rows, tile, lane, valid, x, r, y, acc, staging, rgb);
 }
 
@@ -404,13 +418,15 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         n_rays = (unsigned)children;
         waves = (n_rays + 63) / 64;
     }
-    for (int level = (int)levels - 2; level >= 0; --level) {
+    for (int level = (int)levels - 2; level >= 1; --level) {
         const unsigned w = level_waves[level];
         level_sum_kernel<<<dim3((A.level_rays[level] + 255) / 256), 256, 0, stream>>>((double *)A.terms[level].p, (const uint8_t *)A.links[level].p,
                                                                                      (const uint32_t *)A.ray_of_slot[level].p, w, A.level_rays[level],
                                                                                      (const double *)A.terms[level + 1].p);
     }
-    level_store_kernel<<<dim3(level_waves[0]), 64, 0, stream>>>(camera, rows, (const double *)A.terms[0].p, level_waves[0], blocks_x, rgb);
+    level_store_kernel<<<dim3(level_waves[0]), 64, 0, stream>>>(camera, rows, (const double *)A.terms[0].p, (const uint8_t *)A.links[0].p,
+                                                                levels > 1 ? (const uint32_t *)A.ray_of_slot[0].p : nullptr,
+                                                                levels > 1 ? (const double *)A.terms[1].p : nullptr, level_waves[0], blocks_x, rgb);
     A.levels = levels;
     A.numbered_sorted = sorted;
     if (!numbered) A.ordered = ordered;
