@@ -750,7 +750,8 @@ struct ParkedRays {
 // into the node's space, next record requested over the current one, test while the request is in flight.
 // CONES false: no range-skip node of the table has cones below it (a kernel built without the cone-direction code
 // keeps fewer values across the record loop).
-template <bool STATS, class B, bool CONES = true>
+// EXIT (accumulators that can be settled: occlusion queries): the walk ends once every ray of the wave has its answer.
+template <bool STATS, class B, bool CONES = true, bool EXIT = false>
 __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool active0, double far, B &best, Ctr<STATS> &ctr) {
     const int end = S.n_nodes;
     if (end <= 0) return;
@@ -778,6 +779,9 @@ __device__ __forceinline__ void trace_nested(const SceneK &S, V3 o, V3 d, bool a
     bool have_q = false;
     int i = 0;
     while (i < end) {
+        if constexpr (EXIT) {
+            if (__ballot(active0 && !settled(best)) == 0ull) break;  // every ray of the wave has its answer
+        }
         const NodeWords w = node_words(raw);
         const int xform = uniform(raw.b[9]);  // only read before the next record is requested
         const int kind = w.tag & 0xff;
@@ -922,14 +926,14 @@ __device__ __forceinline__ Closest<TIES> trace(const SceneK &S, V3 o, V3 d, bool
 }
 
 // World::is_shadowed's question about the ray (o, d): a hit with 0 <= t < distance?
-template <int NEST, bool STATS>
+template <int NEST, bool STATS, bool EXIT = false>
 __device__ __forceinline__ bool occluded(const SceneK &S, V3 o, V3 d, bool active, double distance, Ctr<STATS> &ctr) {
     Occluded oc;
     oc.far = distance;
     oc.t = __builtin_nan("");
     if (STATS && active) ctr.add(C_RAYS);
     if constexpr (NEST == 0) trace_flat<STATS>(S, o, d, active, oc, ctr);
-    else trace_nested<STATS, Occluded, nest_cones(NEST)>(S, o, d, active, distance, oc, ctr);
+    else trace_nested<STATS, Occluded, nest_cones(NEST), EXIT>(S, o, d, active, distance, oc, ctr);
     return oc.t < distance;
 }
 

@@ -35,6 +35,12 @@
 // chapter_14 3.63 -> 3.41 ms, generated scene at 1080p 6.2 -> 4.7 ms, at 8K 48.2 -> 46.9 ms).
 // Five waves per SIMD (96 VGPRs, ten to twenty of the traversal's values spilled).  The generated scene at 8K: 55.9 ms
 // at five, 57.2 at six, 67.4 at seven (and, before rays were binned by octant, 63.8 / 62.7 at five / six, 68.9 at four).
+// Shadow traversals stop as soon as every ray of the wave has its occluder.  In render_kernel that test costs more than
+// it saves (a wave's hits lie on many objects); here a wave's rays left one object in one octant, their hits lie
+// together, and so do their shadow rays: chapter_14 at 4K -1 %, the generated scene at 8K -3 %.
+#ifndef RT_LEVEL_SHADOW_EXIT
+#define RT_LEVEL_SHADOW_EXIT true
+#endif
 #ifndef RT_LEVEL_WAVES
 #define RT_LEVEL_WAVES 5
 #endif
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
     const unsigned k_reflect = append(shade && h.reflect, 0u, h.over, reflect(rd, h.normal), h.w_reflect, remaining - 1, best.leaf);
     const unsigned k_refract = append(shade && h.refract, 1u, h.under, h.refract_dir, h.w_refract, remaining - 1, best.leaf);
     if (__ballot(shade) != 0ull) {
-        const bool in_shadow = occluded<NEST, false>(S, h.over, h.shadow_dir, shade, h.light_distance, ctr);  // world.rs:145-148
+        const bool in_shadow = occluded<NEST, false, RT_LEVEL_SHADOW_EXIT>(S, h.over, h.shadow_dir, shade, h.light_distance, ctr);  // world.rs:145-148
         if (shade && !in_shadow) term = term_lit;
     }
     const size_t n = (size_t)io.waves * 64, i = (size_t)wave * 64 + lane;
