@@ -160,8 +160,10 @@ typedef struct rt_scene_info {
     int32_t device;
     int32_t kernel_build; /* which build of the render kernel serves this world: 0 = a table of leaves only (no groups, at
                              most 12 objects), 1 = any table, 2 = a table in which no range of nodes holds a cone,
-                             3 = a large hierarchy, rendered level by level of its ray trees through queues in device
-                             memory (rt_render_device_noalloc serves such a world only for views rendered before) */
+                             3 = a world with groups, rendered level by level of its ray trees through queues in device
+                             memory (rt_render_device_noalloc serves such a world only for views rendered before);
+                             1 and 2 serve worlds with groups only when RT_RENDER_LEVELS=0 was in the environment
+                             when the scene was created */
 } rt_scene_info;
 
 /* struct Computations (rendering/intersections.rs:12-24); `object` is an index into rt_world_desc.objects. */
@@ -198,12 +200,14 @@ int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_rend
 /* The same on device memory, asynchronously on opts->stream: `rgb_device` receives only the rows rendered, packed:
  * (row_end-row_begin)*hsize*3 doubles starting at row_begin, or with bands the selected bands one after another
  * (band_rows*hsize*3 doubles each, the frame's last band possibly shorter).  No host synchronisation unless
- * collect_stats is set -- or the world is a large hierarchy (rt_scene_info.kernel_build 3): such a world is rendered
- * level by level of its ray trees through ray queues in device memory; the FIRST frame of a view (camera, rows, budget)
- * waits on opts->stream once per level to learn how many rays the next level has and lets the handle allocate (and
- * keep) device memory that grows with the frame, about 0.5 KB per pixel; the handle remembers the counts, and later
- * frames of that view are launched without waiting, like any world's.  The frame is complete in stream order when
- * the call returns, as for any world.
+ * collect_stats is set -- or the world has groups (rt_scene_info.kernel_build 3): such a world is rendered level by
+ * level of its ray trees through ray queues in device memory; the FIRST frame of a view (camera, rows, budget) waits on
+ * opts->stream once per level to learn how many rays the next level has, sorts every level's rays, and lets the handle
+ * allocate (and keep) device memory that grows with the frame, about 0.5 KB per pixel; the handle remembers the counts
+ * of 32 views, whose later frames are launched without waiting, like any world's, and for the view rendered last also
+ * the order of its rays and the cost of its waves, so that its later frames run the level kernels alone, most expensive
+ * waves first (only scheduling is remembered, never a result).  The frame is complete in stream order when the call
+ * returns, as for any world.
  * A handle serves ONE render at a time (as `&World` is borrowed for the duration of Camera::render): the scratch in
  * which a launch orders its tiles, the counters and the timing marks belong to the handle, which is `const` here only
  * in the sense that the world it holds does not change.  Launches of one handle on one stream are ordered by the
