@@ -82,6 +82,7 @@ struct LevelArena {
     ArenaBuffer wave_cost, wave_order[LEVELS_MAX];  // shader clocks per wave of the level just rendered; per level: the waves in launch order
     bool ordered = false;                   // wave_order[] belongs to the numbering in place
     int32_t numbered = -1;
+    bool capture_seen = false;              // a call on this handle was captured into a HIP graph: the numbering is never reused again
     bool numbered_sorted = true;            // ... and whether that numbering is the sorted one (RT_LEVELS_SORT)
     size_t device_bytes() const;
 };

@@ -322,12 +322,13 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         }
     if (A.frozen && !known) return hipErrorNotReady;  // (learning a view's ray counts means waiting for the GPU)
     // The view rendered last?  Then its rays' numbering is still in the arena, and it is the same in every frame.
-    // (Not while the stream is being captured: a graph must hold the numbering kernels too, or replaying it after another
-    // view was rendered through this handle would read that view's numbering.)
+    // (Not on a handle through which a call has been captured into a graph: the graph holds the numbering kernels -- it
+    // must, or replaying it after another view went through the handle would read that view's numbering -- and a replay
+    // rewrites the handle's numbering whenever the caller chooses, unseen from here.  Such a handle numbers every frame.)
     hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
     if (stream) RT_TRY(hipStreamIsCapturing(stream, &capture));
-    const bool capturing = capture != hipStreamCaptureStatusNone;
-    const bool numbered = !capturing && known && A.numbered == (int32_t)(known - A.known) && A.numbered_sorted == sorted;
+    if (capture != hipStreamCaptureStatusNone) A.capture_seen = true;
+    const bool numbered = !A.capture_seen && known && A.numbered == (int32_t)(known - A.known) && A.numbered_sorted == sorted;
     if (!numbered) A.numbered = -1;  // (about to be overwritten)
     const size_t lds = lds_bytes<NEST, false>(64);
     unsigned waves = blocks_x * blocks_y * 64, n_rays = waves * 64, levels = 0;
@@ -436,7 +437,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
     A.levels = levels;
     A.numbered_sorted = sorted;
     if (!numbered) A.ordered = ordered;
-    if (known) A.numbered = capturing ? -1 : (int32_t)(known - A.known);
+    if (known) A.numbered = (int32_t)(known - A.known);
     if (!known && remember) {  // remember this view's counts (in place of the entry unused for longest when all are taken)
         uint32_t at = A.n_known;
         if (at == LevelArena::KNOWN_MAX) {

@@ -167,8 +167,7 @@ def test_noalloc_entry_point_allocates_nothing(gpu, rt, orc):
 
 
 def test_noalloc_entry_point_allocates_nothing_level_by_level(gpu, rt, orc, monkeypatch):
-    """The same property for a world rendered level by level of its ray trees (forced here onto chapter_14; large
-    hierarchies take that path by themselves): once rt_render_device has rendered a view -- its ray counts are then
+    """The same property for a world rendered level by level of its ray trees (every world with groups): once rt_render_device has rendered a view -- its ray counts are then
     remembered and its queues exist -- rt_render_device_noalloc renders that view without allocating (hipMemGetInfo) and
     without waiting for the GPU (it can be captured into a HIP graph in global capture mode), with the same bytes."""
     monkeypatch.setenv("RT_RENDER_LEVELS", "1")
@@ -214,11 +213,16 @@ def test_noalloc_entry_point_allocates_nothing_level_by_level(gpu, rt, orc, monk
             rc = lib.hipStreamEndCapture(stream, ctypes.byref(graph))
         assert rc == 0 and graph.value, f"the capture was invalidated (hipStreamEndCapture: {rc})"
         assert lib.hipGraphInstantiate(ctypes.byref(graph_exec), graph, None, None, 0) == 0
-        for _ in range(2):
+        for k in range(3):
             assert lib.hipMemset(b, 0, w * h * 24) == 0 and lib.hipDeviceSynchronize() == 0
             assert lib.hipGraphLaunch(graph_exec, stream) == 0
             assert lib.hipStreamSynchronize(stream) == 0
             assert np.array_equal(hip.fetch(b, (h, w, 3), np.float64), want)
+            # Another (smaller) view through the same handle between two replays: the handle's numbering of rays is
+            # then that view's, and the graph must not depend on it (it numbers its own rays).
+            scene.render_device(cam, a.value, rows=(8, 120), stream=stream.value)
+            scene.render_device_noalloc(cam, a.value, rows=(8, 120), stream=stream.value)
+            assert np.array_equal(hip.fetch(a, (112, w, 3), np.float64), want[8:120]), k
         lib.hipGraphExecDestroy(graph_exec)
         lib.hipGraphDestroy(graph)
     finally:
