@@ -204,8 +204,8 @@ int rt_render(const rt_scene *scene, const rt_camera_desc *camera, const rt_rend
  * level of its ray trees through ray queues in device memory; the FIRST frame of a view (camera, rows, budget) waits on
  * opts->stream once per level to learn how many rays the next level has, sorts every level's rays, and lets the handle
  * allocate (and keep) device memory that grows with the frame, about 0.5 KB per pixel; the handle remembers the counts
- * of 32 views, whose later frames are launched without waiting, like any world's, and for the view rendered last also
- * the order of its rays and the cost of its waves, so that its later frames run the level kernels alone, most expensive
+ * of 32 views, whose later frames are launched without waiting, like any world's, and for the four rendered last also
+ * the order of their rays and the cost of their waves, so that their later frames run the level kernels alone, most expensive
  * waves first (only scheduling is remembered, never a result).  The frame is complete in stream order when the call
  * returns, as for any world.
  * A handle serves ONE render at a time (as `&World` is borrowed for the duration of Camera::render): the scratch in

@@ -49,8 +49,6 @@ constexpr int LEVELS_MAX = RT_MAX_DEPTH + 1;  // level 0 = the rays through the 
 struct LevelArena {
     ArenaBuffer queue_f[2];                // the rays a level reads and the rays it writes: 64 bytes each (origin, direction, weight, remaining budget)
     ArenaBuffer counts, offsets;           // children per kind and wave of the level being rendered, and the same scanned
-    ArenaBuffer index[LEVELS_MAX];         // per level: ray number in the next level -> its slot in the queue
-    ArenaBuffer ray_of_slot[LEVELS_MAX];   // the other way round, per level (kept for the sums: where a ray's children are)
     ArenaBuffer terms[LEVELS_MAX];         // per ray of a level: its term of its pixel's sum, then the sum over its subtree
     ArenaBuffer links[LEVELS_MAX];         // per ray of a level: which of its wave's children are its own
     ArenaBuffer scan_temp;
@@ -79,11 +77,25 @@ struct LevelArena {
     // Which remembered view the numbering in index[] / ray_of_slot[] belongs to (-1: none).  The numbering of a view's
     // rays is the same in every frame, so a frame of the view rendered last skips the counting, the scans and the
     // numbering kernels altogether.
-    ArenaBuffer wave_cost, wave_order[LEVELS_MAX];  // shader clocks per wave of the level just rendered; per level: the waves in launch order
-    bool ordered = false;                   // wave_order[] belongs to the numbering in place
-    int32_t numbered = -1;
-    bool capture_seen = false;              // a call on this handle was captured into a HIP graph: the numbering is never reused again
-    bool numbered_sorted = true;            // ... and whether that numbering is the sorted one (RT_LEVELS_SORT)
+    ArenaBuffer wave_cost;                  // shader clocks per wave of the level just rendered
+    // The numbering of a view's rays: which queue slot holds which ray of every level, and the launch order of every
+    // level's waves.  It is the same in every frame of the view, so a frame of a view whose numbering is still in place
+    // skips the counting, the scans, the sorts and the numbering kernels altogether.  A few are kept (a frame rendered
+    // in row groups is several views), least recently used first to go; every buffer grows to the largest size ever
+    // asked of its kind, so that after the largest view has been rendered nothing grows again.
+    struct Numbering {
+        ArenaBuffer index[LEVELS_MAX];        // per level: ray number in the next level -> its slot in the queue
+        ArenaBuffer ray_of_slot[LEVELS_MAX];  // the other way round (also for the sums: where a ray's children are)
+        ArenaBuffer wave_order[LEVELS_MAX];   // per level: the waves in launch order
+        int32_t view = -1;                    // which remembered view it belongs to (index into known[]; -1: none)
+        bool sorted = true;                   // the sorted numbering (RT_LEVELS_SORT)
+        bool ordered = false;                 // wave_order[] is filled (RT_LEVELS_ORDER)
+        uint64_t used = 0;
+    };
+    static constexpr int NUMBERINGS_MAX = 4;
+    Numbering numberings[NUMBERINGS_MAX];
+    size_t numbering_cap[3][LEVELS_MAX] = {};  // largest index / ray_of_slot / wave_order ever asked for, per level
+    bool capture_seen = false;              // a call on this handle was captured into a HIP graph: no numbering is ever reused again
     size_t device_bytes() const;
 };
 void level_arena_release(LevelArena &arena);

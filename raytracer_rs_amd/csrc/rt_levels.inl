@@ -321,15 +321,60 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
             known->used = ++A.clock;
         }
     if (A.frozen && !known) return hipErrorNotReady;  // (learning a view's ray counts means waiting for the GPU)
-    // The view rendered last?  Then its rays' numbering is still in the arena, and it is the same in every frame.
+    // Is a numbering of this view's rays still in place?  It is the same in every frame.
     // (Not on a handle through which a call has been captured into a graph: the graph holds the numbering kernels -- it
     // must, or replaying it after another view went through the handle would read that view's numbering -- and a replay
     // rewrites the handle's numbering whenever the caller chooses, unseen from here.  Such a handle numbers every frame.)
     hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
     if (stream) RT_TRY(hipStreamIsCapturing(stream, &capture));
     if (capture != hipStreamCaptureStatusNone) A.capture_seen = true;
-    const bool numbered = !A.capture_seen && known && A.numbered == (int32_t)(known - A.known) && A.numbered_sorted == sorted;
-    if (!numbered) A.numbered = -1;  // (about to be overwritten)
+    const int32_t known_at = known ? (int32_t)(known - A.known) : -1;
+    LevelArena::Numbering *N = nullptr;
+    bool numbered = false;
+    if (known && !A.capture_seen)
+        for (LevelArena::Numbering &n : A.numberings)
+            if (n.view == known_at && n.sorted == sorted) N = &n, numbered = true;
+    if (!N) {
+        // Where the new numbering goes: over an old one of the same view, else into an unused set of buffers, else over
+        // the numbering unused for longest.  A caller that must not allocate needs buffers that are large enough: the
+        // ones this view was numbered in when it was first rendered still are (buffers never shrink).
+        auto fits = [&](const LevelArena::Numbering &n) {
+            if (!A.frozen) return true;
+            for (uint32_t level = 0; level + 1 < known->levels; ++level) {
+                const size_t waves_l = level == 0 ? (size_t)blocks_x * blocks_y * 64 : ((size_t)known->level_rays[level] + 63) / 64;
+                if (n.index[level].bytes < (size_t)known->level_rays[level + 1] * sizeof(uint32_t)) return false;
+                if (n.ray_of_slot[level].bytes < waves_l * 128 * sizeof(uint32_t)) return false;
+            }
+            return true;
+        };
+        LevelArena::Numbering *same = nullptr, *unused = nullptr, *oldest = nullptr;
+        for (LevelArena::Numbering &n : A.numberings) {
+            if (!fits(n)) continue;
+            if (known && n.view == known_at) same = same ? same : &n;
+            else if (n.view < 0) unused = unused ? unused : &n;
+            else if (!oldest || n.used < oldest->used) oldest = &n;
+        }
+        N = same ? same : unused ? unused : oldest;
+        if (!N) return hipErrorNotReady;
+        N->view = -1;  // (about to be overwritten)
+    }
+    // (What a numbering's waves cost is recorded with it -- unless the caller must not allocate and the buffers for the
+    // launch orders are not there: then this numbering goes without.)
+    bool record_order = ordered && !numbered;
+    if (record_order && A.frozen)
+        for (uint32_t level = 0; level < known->levels; ++level) {
+            const size_t waves_l = level == 0 ? (size_t)blocks_x * blocks_y * 64 : ((size_t)known->level_rays[level] + 63) / 64;
+            const size_t need = waves_l * sizeof(uint32_t);
+            if (N->wave_order[level].bytes < need || A.wave_cost.bytes < need || A.sort_buf[0].bytes < need || A.sort_buf[1].bytes < need ||
+                A.sort_buf[2].bytes < need)
+                record_order = false;
+        }
+    // (Buffers of a numbering are only ever resized while it is being made, never while it is in use.)
+    auto reserve_numbering = [&](ArenaBuffer &b, size_t need, int kind, int level) {
+        size_t &cap = A.numbering_cap[kind][level];
+        if (need > cap) cap = need;
+        return reserve(b, A.frozen ? need : cap, A.frozen);
+    };
     const size_t lds = lds_bytes<NEST, false>(64);
     unsigned waves = blocks_x * blocks_y * 64, n_rays = waves * 64, levels = 0;
     uint32_t level_waves[LEVELS_MAX] = {};
@@ -344,23 +389,23 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         if (!last) {
             RT_TRY(reserve(A.queue_f[out], (size_t)waves * 128 * 8 * sizeof(double), A.frozen));
             RT_TRY(reserve(A.offsets, table * sizeof(uint32_t), A.frozen));
-            RT_TRY(reserve(A.ray_of_slot[level], (size_t)waves * 128 * sizeof(uint32_t), A.frozen));
+            if (!numbered) RT_TRY(reserve_numbering(N->ray_of_slot[level], (size_t)waves * 128 * sizeof(uint32_t), 1, level));
             if (sorted && !numbered) RT_TRY(reserve(A.key_of_slot, (size_t)waves * 128 * sizeof(uint32_t), A.frozen));
         }
         LevelIO io;
         io.in_f = (const double *)A.queue_f[in].p;
-        io.in_index = level == 0 ? nullptr : (const uint32_t *)A.index[level - 1].p;
+        io.in_index = level == 0 ? nullptr : (const uint32_t *)N->index[level - 1].p;
         io.n_rays = n_rays;
         io.out_f = (double *)A.queue_f[out].p;
         io.out_counts = numbered ? nullptr : (uint32_t *)A.counts.p;
         io.out_keys = sorted && !numbered && !last ? (uint32_t *)A.key_of_slot.p : nullptr;
         io.leaf_bits = leaf_bits;
-        if (ordered && !numbered) {
+        if (record_order) {
             RT_TRY(reserve(A.wave_cost, (size_t)waves * sizeof(uint32_t), A.frozen));
-            RT_TRY(reserve(A.wave_order[level], (size_t)waves * sizeof(uint32_t), A.frozen));
+            RT_TRY(reserve_numbering(N->wave_order[level], (size_t)waves * sizeof(uint32_t), 2, level));
             io.out_cost = (uint32_t *)A.wave_cost.p;
         }
-        if (ordered && numbered && A.ordered) io.wave_order = (const uint32_t *)A.wave_order[level].p;
+        if (ordered && numbered && N->ordered) io.wave_order = (const uint32_t *)N->wave_order[level].p;
         io.waves = waves;
         io.terms = (double *)A.terms[level].p;
         io.links = (uint8_t *)A.links[level].p;
@@ -373,15 +418,15 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         if (level == 0) level_kernel<NEST, TIES, true><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
         else level_kernel<NEST, TIES, false><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
         RT_TRY(hipGetLastError());
-        if (ordered && !numbered) {
+        if (record_order) {
             for (int k = 0; k < 3; ++k) RT_TRY(reserve(A.sort_buf[k], (size_t)waves * sizeof(uint32_t), A.frozen));
             uint32_t *keys_in = (uint32_t *)A.sort_buf[0].p, *keys_out = (uint32_t *)A.sort_buf[1].p, *ids = (uint32_t *)A.sort_buf[2].p;
             level_cost_key_kernel<<<dim3((waves + 255) / 256), 256, 0, stream>>>((const uint32_t *)A.wave_cost.p, waves, keys_in, ids);
             size_t sort_need = 0;
-            RT_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_need, keys_in, keys_out, ids, (uint32_t *)A.wave_order[level].p, (int)waves, 0, 7, stream));
+            RT_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_need, keys_in, keys_out, ids, (uint32_t *)N->wave_order[level].p, (int)waves, 0, 7, stream));
             RT_TRY(reserve(A.scan_temp, sort_need, A.frozen));
             size_t sort_bytes = A.scan_temp.bytes;
-            RT_TRY(hipcub::DeviceRadixSort::SortPairs(A.scan_temp.p, sort_bytes, keys_in, keys_out, ids, (uint32_t *)A.wave_order[level].p, (int)waves, 0, 7, stream));
+            RT_TRY(hipcub::DeviceRadixSort::SortPairs(A.scan_temp.p, sort_bytes, keys_in, keys_out, ids, (uint32_t *)N->wave_order[level].p, (int)waves, 0, 7, stream));
         }
         if (last) break;
         if (numbered) {
@@ -406,21 +451,21 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         }
         if (children == 0) break;
         if (children > 0x3fffffffull) return hipErrorOutOfMemory;
-        RT_TRY(reserve(A.index[level], (size_t)children * sizeof(uint32_t), A.frozen));
-        level_index_kernel<<<dim3((2 * waves + 3) / 4), 256, 0, stream>>>(counts, offsets, waves, (uint32_t *)A.index[level].p,
-                                                                          (uint32_t *)A.ray_of_slot[level].p);
+        RT_TRY(reserve_numbering(N->index[level], (size_t)children * sizeof(uint32_t), 0, level));
+        level_index_kernel<<<dim3((2 * waves + 3) / 4), 256, 0, stream>>>(counts, offsets, waves, (uint32_t *)N->index[level].p,
+                                                                          (uint32_t *)N->ray_of_slot[level].p);
         if (sorted) {  // ... then group them by (kind, octant, leaf), keeping that order within a group
             const unsigned n = (unsigned)children;
             for (int k = 0; k < 3; ++k) RT_TRY(reserve(A.sort_buf[k], (size_t)n * sizeof(uint32_t), A.frozen));
             uint32_t *keys_in = (uint32_t *)A.sort_buf[0].p, *keys_out = (uint32_t *)A.sort_buf[1].p, *vals_out = (uint32_t *)A.sort_buf[2].p;
-            uint32_t *slot_of_ray = (uint32_t *)A.index[level].p;
+            uint32_t *slot_of_ray = (uint32_t *)N->index[level].p;
             level_key_gather_kernel<<<dim3((n + 255) / 256), 256, 0, stream>>>(slot_of_ray, (const uint32_t *)A.key_of_slot.p, n, keys_in);
             size_t sort_need = 0;
             RT_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_need, keys_in, keys_out, slot_of_ray, vals_out, (int)n, 0, (int)leaf_bits + 4, stream));
             RT_TRY(reserve(A.scan_temp, sort_need, A.frozen));
             size_t sort_bytes = A.scan_temp.bytes;
             RT_TRY(hipcub::DeviceRadixSort::SortPairs(A.scan_temp.p, sort_bytes, keys_in, keys_out, slot_of_ray, vals_out, (int)n, 0, (int)leaf_bits + 4, stream));
-            level_renumber_kernel<<<dim3((n + 255) / 256), 256, 0, stream>>>(vals_out, n, slot_of_ray, (uint32_t *)A.ray_of_slot[level].p);
+            level_renumber_kernel<<<dim3((n + 255) / 256), 256, 0, stream>>>(vals_out, n, slot_of_ray, (uint32_t *)N->ray_of_slot[level].p);
         }
         n_rays = (unsigned)children;
         waves = (n_rays + 63) / 64;
@@ -428,16 +473,16 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
     for (int level = (int)levels - 2; level >= 1; --level) {
         const unsigned w = level_waves[level];
         level_sum_kernel<<<dim3((A.level_rays[level] + 255) / 256), 256, 0, stream>>>((double *)A.terms[level].p, (const uint8_t *)A.links[level].p,
-                                                                                     (const uint32_t *)A.ray_of_slot[level].p, w, A.level_rays[level],
+                                                                                     (const uint32_t *)N->ray_of_slot[level].p, w, A.level_rays[level],
                                                                                      (const double *)A.terms[level + 1].p);
     }
     level_store_kernel<<<dim3(level_waves[0]), 64, 0, stream>>>(camera, rows, (const double *)A.terms[0].p, (const uint8_t *)A.links[0].p,
-                                                                levels > 1 ? (const uint32_t *)A.ray_of_slot[0].p : nullptr,
+                                                                levels > 1 ? (const uint32_t *)N->ray_of_slot[0].p : nullptr,
                                                                 levels > 1 ? (const double *)A.terms[1].p : nullptr, level_waves[0], blocks_x, rgb);
     A.levels = levels;
-    A.numbered_sorted = sorted;
-    if (!numbered) A.ordered = ordered;
-    if (known) A.numbered = (int32_t)(known - A.known);
+    if (!numbered) N->sorted = sorted, N->ordered = record_order;
+    N->used = ++A.clock;
+    if (known) N->view = known_at;
     if (!known && remember) {  // remember this view's counts (in place of the entry unused for longest when all are taken)
         uint32_t at = A.n_known;
         if (at == LevelArena::KNOWN_MAX) {
@@ -447,6 +492,8 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         } else {
             A.n_known++;
         }
+        for (LevelArena::Numbering &n : A.numberings)
+            if (n.view == (int32_t)at) n.view = -1;  // (the numbering of the view that is being forgotten)
         LevelArena::Known &e = A.known[at];
         std::memcpy(&e.cam, &camera, sizeof camera);
         std::memcpy(e.rows, view, sizeof view);
@@ -454,7 +501,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         e.levels = levels;
         std::memcpy(e.level_rays, A.level_rays, sizeof e.level_rays);
         e.used = ++A.clock;
-        A.numbered = (int32_t)at;
+        N->view = (int32_t)at;
     }
     return hipGetLastError();
 #undef RT_TRY
@@ -465,8 +512,9 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
 size_t LevelArena::device_bytes() const {
     size_t total = queue_f[0].bytes + queue_f[1].bytes + counts.bytes + offsets.bytes + scan_temp.bytes + key_of_slot.bytes + sort_buf[0].bytes + sort_buf[1].bytes +
                    sort_buf[2].bytes + wave_cost.bytes;
-    for (int k = 0; k < LEVELS_MAX; ++k) total += wave_order[k].bytes;
-    for (int k = 0; k < LEVELS_MAX; ++k) total += index[k].bytes + ray_of_slot[k].bytes + terms[k].bytes + links[k].bytes;
+    for (const Numbering &n : numberings)
+        for (int k = 0; k < LEVELS_MAX; ++k) total += n.index[k].bytes + n.ray_of_slot[k].bytes + n.wave_order[k].bytes;
+    for (int k = 0; k < LEVELS_MAX; ++k) total += terms[k].bytes + links[k].bytes;
     return total;
 }
 
@@ -477,14 +525,18 @@ void level_arena_release(LevelArena &A) {
     };
     for (int k = 0; k < 2; ++k) drop(A.queue_f[k]);
     drop(A.counts), drop(A.offsets), drop(A.scan_temp), drop(A.key_of_slot), drop(A.wave_cost);
-    for (int k = 0; k < LEVELS_MAX; ++k) drop(A.wave_order[k]);
+    for (LevelArena::Numbering &n : A.numberings) {
+        for (int k = 0; k < LEVELS_MAX; ++k) drop(n.index[k]), drop(n.ray_of_slot[k]), drop(n.wave_order[k]);
+        n.view = -1;
+    }
+    for (auto &caps : A.numbering_cap)
+        for (size_t &c : caps) c = 0;
     for (int k = 0; k < 3; ++k) drop(A.sort_buf[k]);
-    for (int k = 0; k < LEVELS_MAX; ++k) drop(A.index[k]), drop(A.ray_of_slot[k]), drop(A.terms[k]), drop(A.links[k]);
+    for (int k = 0; k < LEVELS_MAX; ++k) drop(A.terms[k]), drop(A.links[k]);
     if (A.host_totals) (void)hipHostFree(A.host_totals);
     A.host_totals = nullptr;
     A.levels = 0;
     A.n_known = 0;
-    A.numbered = -1;
 }
 
 // Frames of more pixels than this are rendered in chunks of rows, one after the other through the same arena: the

@@ -187,6 +187,9 @@ def test_repeated_views_are_launched_from_remembered_counts(gpu, rt, orc, levels
         for k in (1, 0, 3):
             for _ in range(3):
                 assert np.array_equal(frame(*views[k]), want[k]), k
+        # a few views in turn (a frame rendered in row groups): the handle keeps the numbering of several
+        for k in (0, 1, 2, 0, 1, 2, 0, 1, 2, 3, 4, 0, 1):
+            assert np.array_equal(frame(*views[k]), want[k]), k
         # the order of a level's rays is no part of the result: frames with the rays left unsorted, of views numbered
         # sorted before, and back
         monkeypatch.setenv("RT_LEVELS_SORT", "0")
