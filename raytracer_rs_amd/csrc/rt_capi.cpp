@@ -264,11 +264,22 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     // per device while that device is current.  A failure only disables that entry point (it reports it).
     (void)rt::static_render_scratch_resolve(device);
 
-    size_t nb = sc->flat.nodes.size() * sizeof(RtNode), sb = sc->flat.surfaces.size() * sizeof(RtSurface);
+    // A table of leaves only (what the kernels built for worlds without groups walk) lies in device memory TWICE, one
+    // copy after the other in front of the inert record: a walk that starts at any record and takes as many records
+    // as the table has then needs no wrap-round (the shadow rays of rt::render_kernel start at the object they leave).
+    const bool leaves_only = sc->flat.max_nesting == 0 && !sc->flat.n_skip_nodes && !sc->flat.n_groups && !sc->flat.reordered && sc->flat.n_tables == 1;
+    std::vector<RtNode> doubled;
+    if (leaves_only && sc->flat.table_records > 1) {
+        const size_t n = sc->flat.table_records - 1;
+        doubled.assign(sc->flat.nodes.begin(), sc->flat.nodes.begin() + (ptrdiff_t)n);
+        doubled.insert(doubled.end(), sc->flat.nodes.begin(), sc->flat.nodes.end());  // the second copy and the inert record
+    }
+    const std::vector<RtNode> &table = doubled.empty() ? sc->flat.nodes : doubled;
+    size_t nb = table.size() * sizeof(RtNode), sb = sc->flat.surfaces.size() * sizeof(RtSurface);
     e = hipMalloc((void **)&sc->d_nodes, nb);  // (every table carries its own inert trailing record)
     if (e == hipSuccess) e = hipMalloc((void **)&sc->d_surfaces, sb ? sb : sizeof(RtSurface));
     if (e == hipSuccess) e = hipMalloc((void **)&sc->d_counters, RT_NUM_COUNTERS * sizeof(unsigned long long));
-    if (e == hipSuccess && nb) e = hipMemcpy(sc->d_nodes, sc->flat.nodes.data(), nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nb) e = hipMemcpy(sc->d_nodes, table.data(), nb, hipMemcpyHostToDevice);
     if (e == hipSuccess && sb) e = hipMemcpy(sc->d_surfaces, sc->flat.surfaces.data(), sb, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         rt_scene *raw = sc.release();
@@ -286,7 +297,7 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     // 0 selects the kernels built for tables of leaves only; a group (even a childless one at the top level) or a
     // range-skip node needs the general ones
     sc->dev.max_nesting = (int32_t)sc->flat.max_nesting;
-    if ((sc->flat.n_skip_nodes || sc->flat.n_groups) && sc->dev.max_nesting < 1) sc->dev.max_nesting = 1;
+    if (!leaves_only && sc->dev.max_nesting < 1) sc->dev.max_nesting = 1;
     sc->dev.any_order = sc->flat.reordered ? 1 : 0;
     sc->dev.cone_nodes = 0;
     for (const RtNode &n : sc->flat.nodes)

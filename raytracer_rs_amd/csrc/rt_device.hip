@@ -706,6 +706,49 @@ __device__ __forceinline__ void trace_flat(const SceneK &S, V3 o, V3 d, bool act
     }
 }
 
+// trace_flat for the occlusion queries of the plain render kernel: the walk starts at record `start` and ends as soon as
+// every ray of the wave has its occluder -- the answer does not depend on the order.  The caller names the record of
+// the object its rays start on: a ray that starts INSIDE a closed object is occluded by that very object, so the shadow
+// rays of a wave inside a glass ball (most rays of a scene with glass in it) are settled by one record instead of all.
+// No wrap-round: a table of leaves lies in memory twice, one copy after the other (rt_scene_create).
+template <bool STATS, class B>
+__device__ __forceinline__ void trace_flat_from(const SceneK &S, V3 o, V3 d, bool active, B &best, Ctr<STATS> &ctr, int start) {
+    if (S.n_nodes <= 0) return;
+    int i = uniform(start >= 0 && start < S.n_nodes ? start : 0);
+    int end = uniform(i + S.n_nodes);
+    NodeRaw raw = node_fetch<false>(S.nodes, i);
+    asm volatile("" ::"s"(raw.b[8]));  // as in trace_flat
+    const double dd = __builtin_fma(d.z, d.z, __builtin_fma(d.y, d.y, d.x * d.x)) * BALL_SHRINK;  // for misses_ball
+    while (i < end) {
+        const NodeWords w = node_words(raw);
+        const int xform = uniform(raw.b[9]);  // only read before the next record is requested
+        const int kind = w.tag & 0xff;
+        bool visit = true;  // wave-uniform
+        // (a ray that has its answer asks for no record)
+        if (xform == RT_XFORM_DIAGONAL_BALL) {
+            visit = __ballot(active && !settled(best) && !misses_ball(raw, o, d, dd)) != 0ull;
+        } else if (kind == RT_PLANE && xform != RT_XFORM_GENERAL) {
+            const double ky = dwords_to_double(raw.a[10], raw.a[11]);
+            visit = __ballot(active && !settled(best) && !plane_behind(ky * o.y + dwords_to_double(raw.a[14], raw.a[15]), ky * d.y)) != 0ull;
+        }
+        NodeRaw nraw;
+        RT_NODE_VISIT(2);
+        if (visit) {
+            V3 lo, ld;
+            to_local(raw, xform, o, d, lo, ld);
+            asm volatile("" : "+v"(lo.x), "+v"(lo.y), "+v"(lo.z), "+v"(ld.x), "+v"(ld.y), "+v"(ld.z));  // the transform is complete
+            nraw = node_fetch<false>(S.nodes, i + 1);
+            hit_leaf<true, STATS, B>(kind, w.tag, lo, ld, w.a0, w.a1, true, w.leaf, best);
+            if (__ballot(active && !settled(best)) == 0ull) end = i;  // every ray of the wave has its answer
+        } else {
+            nraw = node_fetch<false>(S.nodes, i + 1);
+        }
+        pin(best);  // as in trace_flat
+        raw = nraw;
+        i = uniform(i + 1);
+    }
+}
+
 // Where a traversal parks the ray of an outer sibling list while it walks a group's children: the ray of nesting
 // level 1 in the wave's LDS (field-major, one 8-byte column per lane: conflict-free), deeper levels in a per-lane
 // array in scratch memory (indexed by the wave-uniform level, so a whole wave's access is one contiguous run).  The
@@ -926,13 +969,20 @@ __device__ __forceinline__ Closest<TIES> trace(const SceneK &S, V3 o, V3 d, bool
 }
 
 // World::is_shadowed's question about the ray (o, d): a hit with 0 <= t < distance?
+#ifndef RT_FLAT_SHADOW_ROTATE
+#define RT_FLAT_SHADOW_ROTATE true
+#endif
+// `start` (flat tables): the record of the object the wave's rays start on, or -1.
 template <int NEST, bool STATS, bool EXIT = false>
-__device__ __forceinline__ bool occluded(const SceneK &S, V3 o, V3 d, bool active, double distance, Ctr<STATS> &ctr) {
+__device__ __forceinline__ bool occluded(const SceneK &S, V3 o, V3 d, bool active, double distance, Ctr<STATS> &ctr, int start = -1) {
     Occluded oc;
     oc.far = distance;
     oc.t = __builtin_nan("");
     if (STATS && active) ctr.add(C_RAYS);
-    if constexpr (NEST == 0) trace_flat<STATS>(S, o, d, active, oc, ctr);
+    if constexpr (NEST == 0) {
+        if constexpr (RT_FLAT_SHADOW_ROTATE && EXIT && !STATS) trace_flat_from<STATS>(S, o, d, active, oc, ctr, start);
+        else trace_flat<STATS>(S, o, d, active, oc, ctr);
+    }
     else trace_nested<STATS, Occluded, nest_cones(NEST), EXIT>(S, o, d, active, distance, oc, ctr);
     return oc.t < distance;
 }
@@ -1312,7 +1362,10 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
         }
         RT_TIC(tm2);
         if (__ballot(shade) != 0ull) {
-            const bool in_shadow = occluded<NEST, STATS>(S, sro, srd, shade, h_dist, ctr);  // world.rs:145-148
+            // (flat tables hold the objects in the reference's order, one record per leaf: record = leaf number)
+            int start = -1;
+            if constexpr (NEST == 0 && !STATS) start = __builtin_amdgcn_readlane(best.leaf, __builtin_ctzll(__ballot(shade)));
+            const bool in_shadow = occluded<NEST, STATS, NEST == 0>(S, sro, srd, shade, h_dist, ctr, start);  // world.rs:145-148
             if (shade && !in_shadow) {
                 if constexpr (SHARE) term = acc_lit;
                 else acc = acc_lit;
