@@ -969,6 +969,9 @@ __device__ __forceinline__ Closest<TIES> trace(const SceneK &S, V3 o, V3 d, bool
 }
 
 // World::is_shadowed's question about the ray (o, d): a hit with 0 <= t < distance?
+#ifndef RT_OWN_SHADOW
+#define RT_OWN_SHADOW true
+#endif
 #ifndef RT_FLAT_SHADOW_ROTATE
 #define RT_FLAT_SHADOW_ROTATE true
 #endif
@@ -1084,9 +1087,10 @@ __device__ __attribute__((noinline)) double pow_general(double x, double y) { re
 // BEFORE the shadow ray is traced: returns the result for in_shadow = true in `shadowed` (ambient only: the reference
 // adds black diffuse and specular terms, which changes nothing) and the result for in_shadow = false in `lit`.
 // `flags` bit 0: the diffuse branch is taken when not in shadow; bit 1: powf is evaluated then.
+// need_lit false: the caller knows the point to be in shadow; `lit` is then not computed (it comes back as `shadowed`).
 template <bool STATS>
 __device__ __forceinline__ void lighting(const RtSurface *s, const RtLight &light, V3 point, V3 object_point, V3 eye,
-                                         V3 normal, V3 &shadowed, V3 &lit, int &flags, Ctr<STATS> &ctr) {
+                                         V3 normal, V3 &shadowed, V3 &lit, int &flags, Ctr<STATS> &ctr, bool need_lit = true) {
     V3 color;
     if (s->pattern_kind != RT_PATTERN_NONE) {
         V3 pattern_point = mul_point(s->pat_inv, object_point);
@@ -1098,13 +1102,14 @@ __device__ __forceinline__ void lighting(const RtSurface *s, const RtLight &ligh
     V3 li = mk(light.intensity[0], light.intensity[1], light.intensity[2]);
     V3 lp = mk(light.position[0], light.position[1], light.position[2]);
     V3 effective = mk(color.x * li.x, color.y * li.y, color.z * li.z);
-    V3 lv = lp - point;
-    lv = div_by_magnitude(lv, magnitude(lv));
     V3 ambient = effective * s->ambient;
-    double ldn = dot(lv, normal);
     shadowed = ambient;
     lit = ambient;
     flags = 0;
+    if (!need_lit) return;
+    V3 lv = lp - point;
+    lv = div_by_magnitude(lv, magnitude(lv));
+    double ldn = dot(lv, normal);
     if (ldn >= 0.0) {
         flags = 1;
         V3 diffuse = (effective * s->diffuse) * ldn;
@@ -1159,6 +1164,7 @@ struct HitShade {
     int flags;                 // (counting kernel) bit 0: the lit colour has a diffuse term, bit 1: a specular one
     bool reflect, refract;     // which children the hit spawns
     bool from_inside;
+    bool own_shadow;           // the hit is known to lie in its own object's shadow: `lit` is not computed and no shadow ray need be walked
     V3 over, under;            // over_point, under_point (intersections.rs:60-63): where the children start
     V3 normal;                 // at the hit, turned towards the eye: the reflection's direction is reflect(rd, normal) (intersections.rs:62)
     V3 refract_dir;
@@ -1166,7 +1172,7 @@ struct HitShade {
     V3 shadow_dir;             // from `over` towards the light, normalised
     double light_distance;
 };
-template <bool DIAGONAL, bool STATS>
+template <bool DIAGONAL, bool STATS, bool OWN_SHADOW = false>
 __device__ __forceinline__ void shade_hit(const RtLight &light, V3 light_pos, const RtSurface *s, V3 ro, V3 rd, double t, double w, int remaining,
                                           HitShade &h, Ctr<STATS> &ctr) {
     V3 point = ro + rd * t;
@@ -1178,7 +1184,23 @@ __device__ __forceinline__ void shade_hit(const RtLight &light, V3 light_pos, co
     h.over = point + normal * EPS;
     ctr.add(C_SHADES);
     h.flags = 0;
-    lighting<STATS>(s, light, point, object_point, eye, normal, h.shadowed, h.lit, h.flags, ctr);
+    h.own_shadow = false;
+    if constexpr (OWN_SHADOW) {
+        // A hit from inside a sphere that the light is well outside of (RT_SURFACE_LIGHT_OUTSIDE): the shadow ray starts
+        // strictly inside the sphere -- c = |o'|^2 - 1 of the reference's quadratic (sphere.rs:51-74) is below -1e-6 here,
+        // and the reference's own o' (the ray taken through the local inverses of the enclosing groups, world.rs:53-58)
+        // differs from this one by less than 1e-8 (rt_flatten.cpp), so its c is negative too, by far more than the
+        // rounding of b^2 - 4ac: the quadratic has a root t2 > 0 -- and the light lies at least as far beyond the
+        // sphere's surface as half its longest chord, so t2 <= 2/3 of the light's distance: World::is_shadowed
+        // (world.rs:128-149) answers true whatever else the ray would meet.  Neither the lit colour nor the shadow
+        // walk is needed for such a hit (Material::lighting returns the ambient term alone for a point in shadow).
+        if (h.from_inside && (s->flags & RT_SURFACE_LIGHT_OUTSIDE) != 0) {
+            const double *m = s->inv_world;
+            const V3 p = s->xform != RT_XFORM_GENERAL ? mk(m[0] * h.over.x + m[3], m[5] * h.over.y + m[7], m[10] * h.over.z + m[11]) : mul_point(m, h.over);
+            h.own_shadow = dot(p, p) - 1.0 < -1e-6;
+        }
+    }
+    lighting<STATS>(s, light, point, object_point, eye, normal, h.shadowed, h.lit, h.flags, ctr, !h.own_shadow);
 
     const double reflectivity = s->reflectivity;
     const double transparency = s->transparency;
@@ -1325,10 +1347,12 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
         V3 sro = ro, srd = rd;    // the shadow ray
         double h_dist = 0.0;
         int h_flags = 0;
+        bool own_shadow = false;
         if (shade) {
             HitShade h;
-            shade_hit<NEST == 0, STATS>(S.light, light_pos, S.surfaces + best.leaf, ro, rd, best.t, w, remaining, h, ctr);
+            shade_hit<NEST == 0, STATS, RT_OWN_SHADOW && !STATS>(S.light, light_pos, S.surfaces + best.leaf, ro, rd, best.t, w, remaining, h, ctr);
             h_flags = h.flags;
+            own_shadow = h.own_shadow;
             if constexpr (SHARE) {  // the two candidate terms; the sum is formed in the owner's lane, below
                 acc_lit = h.lit * w;
                 term = h.shadowed * w;
@@ -1362,10 +1386,14 @@ __device__ __forceinline__ void radiance(const SceneK &S, bool valid, V3 ro, V3 
         }
         RT_TIC(tm2);
         if (__ballot(shade) != 0ull) {
-            // (flat tables hold the objects in the reference's order, one record per leaf: record = leaf number)
-            int start = -1;
-            if constexpr (NEST == 0 && !STATS) start = __builtin_amdgcn_readlane(best.leaf, __builtin_ctzll(__ballot(shade)));
-            const bool in_shadow = occluded<NEST, STATS, NEST == 0>(S, sro, srd, shade, h_dist, ctr, start);  // world.rs:145-148
+            const bool walk = shade && !own_shadow;  // the shadow rays that need a traversal
+            bool in_shadow = own_shadow;
+            if (__ballot(walk) != 0ull) {
+                // (flat tables hold the objects in the reference's order, one record per leaf: record = leaf number)
+                int start = -1;
+                if constexpr (NEST == 0 && !STATS) start = __builtin_amdgcn_readlane(best.leaf, __builtin_ctzll(__ballot(walk)));
+                in_shadow = occluded<NEST, STATS, NEST == 0>(S, sro, srd, walk, h_dist, ctr, start) || own_shadow;  // world.rs:145-148
+            }
             if (shade && !in_shadow) {
                 if constexpr (SHARE) term = acc_lit;
                 else acc = acc_lit;

@@ -70,7 +70,13 @@ struct RtSurface {
     int32_t pattern_kind;  // RT_PATTERN_*
     int32_t object;
     int32_t xform;         // RT_XFORM_* of inv_world (never RT_XFORM_DIAGONAL_BALL)
+    int32_t flags;         // RT_SURFACE_*
+    int32_t _pad;
 };
+// A top-level sphere that the light is well outside of: in the sphere's own space the light lies at least two radii from
+// the centre.  A shadow ray that starts strictly inside such a sphere leaves it before it reaches the light, so the
+// point it starts from is in the sphere's own shadow whatever else the world holds (rt::shade_hit uses this).
+#define RT_SURFACE_LIGHT_OUTSIDE 1
 
 struct RtLight {
     double position[3];

@@ -678,6 +678,32 @@ int flatten_world(const rt_world_desc &world, FlatScene &out, std::string &err) 
         out.light.position[i] = world.light_position[i];
         out.light.intensity[i] = world.light_intensity[i];
     }
+    // RT_SURFACE_LIGHT_OUTSIDE: the light in the sphere's own space, |p|^2 >= 4 (anything not finite fails the test).
+    // The device decides "strictly inside" from inverse(world_transformation) applied to a point on the sphere, the
+    // reference from the local inverses of the enclosing groups one after the other (world.rs:53-58): the two agree to
+    // within a few ulp of the largest term of the products, 1e-15 * sum_j |m_ij| |x_j|.  With that sum bounded by 1e6 for
+    // every point of the sphere they agree to 1e-8 in the sphere's space, a hundredth of the margin the device demands.
+    if (world.has_light)
+        for (RtSurface &s : out.surfaces) {
+            if (s.kind != RT_SPHERE) continue;
+            const double *m = s.inv_world, *l = world.light_position;
+            auto W = Matrix4::from_array(world.objects[s.object].world_transformation);
+            const Vec3 centre = mul_point(W, Vec3{0.0, 0.0, 0.0});
+            double radius = 0.0;  // no point of the sphere is further than this from the centre along any world axis (largest row sum)
+            for (int r = 0; r < 3; ++r) {
+                const double *w = world.objects[s.object].world_transformation + 4 * r;
+                radius = std::fmax(radius, std::fabs(w[0]) + std::fabs(w[1]) + std::fabs(w[2]));
+            }
+            double p[3], terms = 0.0;
+            for (int r = 0; r < 3; ++r) {
+                p[r] = m[4 * r] * l[0] + m[4 * r + 1] * l[1] + m[4 * r + 2] * l[2] + m[4 * r + 3];
+                const double t = std::fabs(m[4 * r]) * (std::fabs(centre.x) + radius) + std::fabs(m[4 * r + 1]) * (std::fabs(centre.y) + radius) +
+                                 std::fabs(m[4 * r + 2]) * (std::fabs(centre.z) + radius) + std::fabs(m[4 * r + 3]);
+                terms = std::fmax(terms, t);
+            }
+            const double d2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+            if (d2 >= 4.0 && d2 < 1e300 && terms <= 1e6) s.flags |= RT_SURFACE_LIGHT_OUTSIDE;
+        }
     return RT_OK;
 }
 

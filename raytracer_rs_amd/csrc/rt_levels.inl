@@ -142,18 +142,20 @@ __global__ __launch_bounds__(64, RT_LEVEL_WAVES) void level_kernel(DeviceScene s
     V3 term_lit = mk(0.0, 0.0, 0.0), term = mk(0.0, 0.0, 0.0);
     HitShade h;
     h.reflect = h.refract = false;
+    h.own_shadow = false;
     h.over = h.under = ro, h.normal = h.refract_dir = h.shadow_dir = rd;
     h.w_reflect = h.w_refract = h.light_distance = 0.0;
     if (shade) {
-        shade_hit<false, false>(S.light, light_pos, S.surfaces + best.leaf, ro, rd, best.t, w, remaining, h, ctr);
+        shade_hit<false, false, RT_OWN_SHADOW>(S.light, light_pos, S.surfaces + best.leaf, ro, rd, best.t, w, remaining, h, ctr);
         term_lit = h.lit * w;
         term = h.shadowed * w;
     }
     const unsigned k_reflect = append(shade && h.reflect, 0u, h.over, reflect(rd, h.normal), h.w_reflect, remaining - 1, best.leaf);
     const unsigned k_refract = append(shade && h.refract, 1u, h.under, h.refract_dir, h.w_refract, remaining - 1, best.leaf);
-    if (__ballot(shade) != 0ull) {
-        const bool in_shadow = occluded<NEST, false, RT_LEVEL_SHADOW_EXIT>(S, h.over, h.shadow_dir, shade, h.light_distance, ctr);  // world.rs:145-148
-        if (shade && !in_shadow) term = term_lit;
+    const bool walk = shade && !h.own_shadow;  // (a hit known to lie in its own object's shadow needs no shadow ray walked)
+    if (__ballot(walk) != 0ull) {
+        const bool in_shadow = occluded<NEST, false, RT_LEVEL_SHADOW_EXIT>(S, h.over, h.shadow_dir, walk, h.light_distance, ctr);  // world.rs:145-148
+        if (walk && !in_shadow) term = term_lit;
     }
     const size_t n = (size_t)io.waves * 64, i = (size_t)wave * 64 + lane;
     io.terms[3 * i] = term.x;
