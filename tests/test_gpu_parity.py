@@ -1153,6 +1153,107 @@ def test_render_with_zero_budget(gpu, rt, orc):
     assert np.array_equal(default, five)
 
 
+def test_hits_from_inside_glass_balls_in_their_own_shadow(gpu, rt, orc, monkeypatch):
+    """The render kernels walk no shadow ray (and compute no lit colour) for a hit from inside a sphere that the light is
+    well outside of.  Glass balls for which that proof must hold and balls for which it must not be attempted -- the
+    light INSIDE one, the light just outside another, a ball a hundred units across (the point the shadow ray starts
+    from is then inside by less than the margin demanded), a tiny one, stretched ones, balls inside scaled and rotated
+    groups -- against the oracle, as a single launch and level by level."""
+    import tomli
+
+    glass = """
+[objects.material]
+color = [0.9, 0.95, 1.0]
+diffuse = 0.3
+ambient = 0.1
+specular = 0.9
+shininess = 200.0
+reflectivity = 0.6
+transparency = 0.8
+refractive_index = 1.4
+"""
+    kid_glass = glass.replace("[objects.material]", "[objects.children.material]")
+
+    def ball(translate, scale, extra=""):
+        return f"""
+[[objects]]
+type = "sphere"
+[objects.transform]
+scale = [{scale[0]}, {scale[1]}, {scale[2]}]
+{extra}translate = [{translate[0]}, {translate[1]}, {translate[2]}]
+{glass}"""
+
+    text = """
+[camera]
+width = 192
+height = 128
+fov = 70.0
+from = [0.0, 2.0, -9.0]
+to = [0.0, 1.0, 0.0]
+up = [0.0, 1.0, 0.0]
+[light]
+position = [-2.0, 1.0, -1.0]
+intensity = [1.0, 1.0, 1.0]
+[[objects]]
+type = "plane"
+[objects.material]
+color = [0.8, 0.8, 0.8]
+reflectivity = 0.2
+"""
+    text += ball((-2.0, 1.0, -1.0), (1.0, 1.0, 1.0))            # the light is at its centre
+    text += ball((-0.2, 1.0, -1.0), (1.0, 1.0, 1.0))            # the light 1.8 radii from its centre: outside, not "well outside"
+    text += ball((2.5, 1.0, 0.0), (1.0, 1.0, 1.0))              # an ordinary one
+    text += ball((0.5, 0.3, -3.0), (0.3, 0.3, 0.3))
+    text += ball((4.0, 0.05, -4.0), (0.05, 0.05, 0.05))         # tiny (much smaller and the reference calls its matrix singular)
+    text += ball((0.0, 50.0, 120.0), (50.0, 50.0, 50.0))        # huge
+    text += ball((-4.0, 0.8, 1.0), (1.5, 0.8, 0.4), "rotate_y = 35.0\n")  # stretched and turned
+    text += f"""
+[[objects]]
+type = "group"
+[objects.transform]
+scale = [0.5, 2.0, 0.5]
+rotate_z = 20.0
+translate = [1.0, 1.0, 2.5]
+[[objects.children]]
+type = "sphere"
+{kid_glass}
+[[objects.children]]
+type = "group"
+[objects.children.transform]
+rotate_x = 40.0
+translate = [2.5, 0.0, 0.0]
+[[objects.children.children]]
+type = "sphere"
+[objects.children.children.transform]
+scale = [0.7, 0.7, 1.2]
+{glass.replace("[objects.material]", "[objects.children.children.material]")}
+"""
+    ocam, oworld = orc.scene_from_dict(tomli.loads(text))
+    ref = orc.render(ocam, oworld, threads=16)
+    for levels in ("0", "1"):
+        monkeypatch.setenv("RT_RENDER_LEVELS", levels)
+        sf = rt.SceneFile.from_str(text)
+        cam, world = sf.build_camera(), sf.build_world()
+        scene = world.scene()
+        img, _ = scene.render(cam)
+        assert_frames_match(orc, img, ref)
+        counted, st = scene.render(cam, stats=True)  # (the counting kernel walks every shadow ray)
+        assert np.abs(img - counted).max() <= 1e-13
+        assert st.refract > 0 and st.shadow > 0
+        world.release_scene()
+    # ... and the same balls without the group, through the kernel for worlds without groups
+    flat = text[:text.index('[[objects]]\ntype = "group"')]
+    ocam, oworld = orc.scene_from_dict(tomli.loads(flat))
+    sf = rt.SceneFile.from_str(flat)
+    cam, world = sf.build_camera(), sf.build_world()
+    scene = world.scene()
+    assert scene.info().kernel_build == 0
+    img, _ = scene.render(cam)
+    assert_frames_match(orc, img, orc.render(ocam, oworld, threads=16))
+    counted, _ = scene.render(cam, stats=True)
+    assert np.array_equal(img, counted)
+
+
 # --------------------------------------------------------------------------- full size
 def test_full_4k_frame(gpu, rt, orc):
     """The benchmark configuration itself: chapter_11 at 3840x2160, whole frame against the oracle, ray count exact,
