@@ -711,7 +711,7 @@ def main() -> None:
                                  "the reference's rounding, so its own ceiling is half of peak; `achieved` and `frac` price "
                                  "the REFERENCE's work for the same rays (every ray against every object, 33 flops per "
                                  "ray transform), as the roofline contract asks; the kernel executes 9 per "
-                                 "scale-and-translate inverse and skips a sphere or plane that no ray of a wave can hit: "
+                                 "scale-and-translate inverse and skips a sphere or plane that no ray of a wave can hit, ends a shadow walk when every ray of the wave has its occluder, and answers the shadow query of a hit from inside a sphere by proof (the sphere's own shadow) instead of a walk: "
                                  "executed_flops (PMC) is what it issued and frac_executed prices that"},
         }
         # the committed PMC figures are per launch of the WHOLE frame: they describe a one-GPU run only
