@@ -1252,9 +1252,13 @@ __device__ __forceinline__ void shade_hit(const RtLight &light, V3 light_pos, co
     }
     h.normal = normal;
     h.under = point - normal * EPS;
-    V3 v = light_pos - h.over;  // World::is_shadowed (rendering/world.rs:128-141)
-    h.light_distance = magnitude(v);
-    h.shadow_dir = div_by_magnitude(v, h.light_distance);
+    h.light_distance = 0.0;
+    h.shadow_dir = rd;
+    if (!h.own_shadow) {  // (no shadow ray is walked for a hit that has its answer)
+        V3 v = light_pos - h.over;  // World::is_shadowed (rendering/world.rs:128-141)
+        h.light_distance = magnitude(v);
+        h.shadow_dir = div_by_magnitude(v, h.light_distance);
+    }
     ctr.add(C_SHADOW);
 }
 
