@@ -74,18 +74,19 @@ struct rt_scene_file {
 namespace {
 
 // Which worlds are rendered level by level (rt::launch_render_levels): every world with groups.  Measured on MI355X, GPU
-// time per frame of a repeated view, single launch / levels: chapter_14 (327 leaves) 1.70 / 0.80 ms at 320x200, 2.06 /
-// 1.16 at 1280x720, 4.47 / 4.18 at 3840x2160; generated hierarchies of 101 ... 10 001 leaves at 3840x2160 between 6 % and
-// 36 % faster (the single launch waits for its longest waves: the tiles whose 64 ray trees are all deep).  The price: a
+// time per frame of a repeated view, single launch / levels: chapter_14 (327 leaves) 1.68 / 0.68 ms at 320x200, 2.01 /
+// 0.71 at 1280x720, 4.30 / 3.21 at 3840x2160; generated hierarchies of 101 ... 10 001 leaves at 3840x2160 between 30 % and
+// 56 % faster (the single launch waits for its longest waves: the tiles whose 64 ray trees are all deep).  The price: a
 // view's first frame waits for the GPU after every level, and the handle keeps ray queues that grow with the frame.
-// RT_RENDER_LEVELS=0 / 1 in the environment, read when a scene is created, forces the choice for every world with groups
-// (worlds without groups always take the single launch); RT_LEVELS_MIN_LEAVES is there should small worlds ever need it.
-constexpr uint32_t RT_LEVELS_MIN_LEAVES = 0;
-bool render_by_levels(int max_nesting, uint32_t n_leaves) {
+// A world WITHOUT groups whose table has range-skip nodes (more than twelve objects) keeps the single launch: chapter_12
+// (13 cubes) 0.89 / 1.09 ms at 3840x2160 -- its ray trees are shallow and a queue entry costs more than it saves.
+// RT_RENDER_LEVELS=0 / 1 in the environment, read when a scene is created, forces the choice for every world whose table
+// has groups or range-skip nodes (a table of leaves only always takes the single launch).
+bool render_by_levels(int max_nesting, uint32_t n_groups) {
     if (max_nesting <= 0) return false;
     const char *e = getenv("RT_RENDER_LEVELS");
     if (e && (e[0] == '0' || e[0] == '1') && e[1] == 0) return e[0] == '1';
-    return n_leaves >= RT_LEVELS_MIN_LEAVES;
+    return n_groups > 0;
 }
 
 thread_local std::string g_error;
@@ -306,7 +307,7 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     // In a flat scene without reflective or transparent surfaces every pixel costs one or two rays over the same
     // few objects: nothing to gain from launching the tiles in any particular order.
     sc->uneven = sc->dev.max_nesting > 0;
-    sc->by_levels = render_by_levels(sc->dev.max_nesting, sc->flat.n_leaves);
+    sc->by_levels = render_by_levels(sc->dev.max_nesting, sc->flat.n_groups);
     for (const RtSurface &s : sc->flat.surfaces) sc->uneven = sc->uneven || s.reflectivity != 0.0 || s.transparency != 0.0;
     *out = sc.release();
     return RT_OK;
