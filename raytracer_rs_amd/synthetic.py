@@ -181,3 +181,46 @@ def random_scene(seed: int, width: int = 64, height: int = 48, n_top: int = 6) -
                 else:
                     L += leaf("objects.children", 1.5, False)
     return "\n".join(L) + "\n"
+
+
+def flat_scene(seed: int) -> str:
+    """A world WITHOUT groups and with at most twelve objects (the table-of-leaves kernels): mostly glass and mirror
+    balls, some stretched or turned, a floor, now and then a cube or a cylinder; the light anywhere -- above the scene,
+    close to a ball, inside one."""
+    rng = SplitMix64(seed)
+    u = rng.uniform
+    n = 3 + rng.below(9)
+    centres = [(u(-3, 3), u(0.3, 2.0), u(-3, 3)) for _ in range(n)]
+    where = rng.below(4)
+    if where == 0:
+        light = (u(-10, 10), u(4, 10), u(-10, -2))
+    elif where == 1:  # inside or just outside some ball
+        c = centres[rng.below(n)]
+        light = (c[0] + u(-0.8, 0.8), c[1] + u(-0.8, 0.8), c[2] + u(-0.8, 0.8))
+    elif where == 2:
+        light = (u(-4, 4), u(0.2, 3), u(-4, 4))
+    else:
+        light = (u(-10, -4), 10.0, -10.0)
+    L = ["[camera]", "width = 160", "height = 100", f"fov = {u(50, 80)}", f"from = [{u(-2, 2)}, {u(1.0, 4.0)}, -8.0]",
+         "to = [0.0, 0.8, 0.0]", "up = [0.0, 1.0, 0.0]", "[light]", f"position = [{light[0]}, {light[1]}, {light[2]}]",
+         "intensity = [1.0, 0.95, 0.9]", "[[objects]]", 'type = "plane"', "[objects.material]", "color = [0.7, 0.7, 0.7]",
+         f"reflectivity = {u(0.0, 0.5)}", f"transparency = {0.3 if rng.below(3) == 0 else 0.0}", "refractive_index = 1.4"]
+    for k in range(n):
+        kind = ["sphere", "sphere", "sphere", "sphere", "cube", "cylinder"][rng.below(6)]
+        s = u(0.2, 1.2)
+        scale = (s, s, s) if rng.below(3) else (s * u(0.5, 1.5), s * u(0.5, 1.5), s * u(0.5, 1.5))
+        L += ["[[objects]]", f'type = "{kind}"']
+        if kind == "cylinder":
+            L += ["minimum = -1.0", "maximum = 1.0", f"closed = {'true' if rng.below(2) else 'false'}"]
+        L += ["[objects.transform]", f"scale = [{scale[0]}, {scale[1]}, {scale[2]}]"]
+        if rng.below(3) == 0:
+            L += [f"rotate_y = {u(0, 180)}", f"rotate_x = {u(0, 90)}"]
+        L += [f"translate = [{centres[k][0]}, {centres[k][1]}, {centres[k][2]}]", "[objects.material]",
+              f"color = [{u(0.2, 1)}, {u(0.2, 1)}, {u(0.2, 1)}]", f"ambient = {u(0, 0.2)}", f"diffuse = {u(0.1, 0.8)}",
+              f"specular = {u(0, 0.9)}", f"shininess = {float(10 + rng.below(290))}"]
+        m = rng.below(4)
+        if m >= 1:
+            L += [f"transparency = {u(0.4, 1.0)}", f"refractive_index = {u(1.0, 1.8)}"]
+        if m >= 2:
+            L += [f"reflectivity = {u(0.2, 0.9)}"]
+    return "\n".join(L) + "\n"

@@ -1254,6 +1254,30 @@ scale = [0.7, 0.7, 1.2]
     assert np.array_equal(img, counted)
 
 
+@pytest.mark.parametrize("seed", [501, 502, 505, 511, 517, 523, 531, 540, 556, 577, 579])
+def test_random_worlds_without_groups(gpu, rt, orc, seed):
+    """The table-of-leaves kernels on random worlds of up to twelve objects: glass and mirror balls (stretched, turned),
+    cubes, cylinders, a floor that is transparent now and then, the light above the scene, close to a ball or inside
+    one.  Against the oracle, and the plain kernel (shadow walks that start at the object left and stop early, hits
+    proved to lie in their own ball's shadow) bit for bit against the counting kernel (which walks everything)."""
+    import tomli
+
+    from raytracer_rs_amd import synthetic
+
+    text = synthetic.flat_scene(seed)
+    ocam, oworld = orc.scene_from_dict(tomli.loads(text))
+    sf = rt.SceneFile.from_str(text)
+    cam, world = sf.build_camera(), sf.build_world()
+    scene = world.scene()
+    assert scene.info().kernel_build == 0
+    img, _ = scene.render(cam)
+    oc = orc.Counters()
+    assert_frames_match(orc, img, orc.render(ocam, oworld, threads=16, counters=oc))
+    counted, st = scene.render(cam, stats=True)
+    counters_equal(st, oc)
+    assert np.array_equal(img, counted)
+
+
 # --------------------------------------------------------------------------- full size
 def test_full_4k_frame(gpu, rt, orc):
     """The benchmark configuration itself: chapter_11 at 3840x2160, whole frame against the oracle, ray count exact,

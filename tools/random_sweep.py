@@ -12,6 +12,8 @@ import raytracer_rs_amd as rt  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from raytracer_rs_amd import synthetic  # noqa: E402
 
+
+
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 worst = 0.0
@@ -32,4 +34,19 @@ for seed in range(first, first + count):
         print(f"seed {seed} n_top {n_top} leaves {info.n_leaves} nesting {info.max_nesting} build {info.kernel_build}: max|d| {d:.2e}", flush=True)
         assert d <= 1e-11, (seed, mode, d)
         world.release_scene()
+for seed in range(first, first + 2 * count):
+    text = synthetic.flat_scene(seed)
+    ocam, oworld = orc.scene_from_dict(tomli.loads(text))
+    ref = orc.render(ocam, oworld, threads=16)
+    sf = rt.SceneFile.from_str(text)
+    cam, world = sf.build_camera(), sf.build_world()
+    scene = world.scene()
+    img, _ = scene.render(cam)
+    counted, _ = scene.render(cam, stats=True)
+    d = float(np.abs(img - ref).max())
+    worst = max(worst, d)
+    info = scene.info()
+    print(f"flat seed {seed} leaves {info.n_leaves} build {info.kernel_build}: max|d| {d:.2e}  plain == counting kernel: {np.array_equal(img, counted)}", flush=True)
+    assert d <= 1e-11 and info.kernel_build == 0 and np.array_equal(img, counted), (seed, d)
+    world.release_scene()
 print("worst", worst)
