@@ -416,7 +416,7 @@ hipError_t render_levels(const DeviceScene &scene, const RtCameraDev &camera, co
         A.level_rays[level] = n_rays;
         levels = level + 1;
         uint32_t *counts = (uint32_t *)A.counts.p, *offsets = (uint32_t *)A.offsets.p;
-        if (!last && !numbered) RT_TRY(hipMemsetAsync(counts, 0, table * sizeof(uint32_t), stream));  // (the last entry of every bin must read as zero)
+        if (!last && !numbered) RT_TRY(hipMemsetAsync(counts, 0, table * sizeof(uint32_t), stream));  // (the last entry of either kind must read as zero)
         if (level == 0) level_kernel<NEST, TIES, true><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
         else level_kernel<NEST, TIES, false><<<dim3(waves), 64, lds, stream>>>(scene, camera, rows, max_depth, io);
         RT_TRY(hipGetLastError());
