@@ -1314,6 +1314,11 @@ def test_which_build_of_the_render_kernel_serves_which_world(gpu, rt, monkeypatc
     ch14 = rt.SceneFile.from_file(scene_path("chapter_14")).build_world()
     large = rt.SceneFile.from_str(synthetic.large_scene(64, 36)).build_world()
     assert (build(ch11), build(ch14), build(large)) == (0, 3, 3)
+    # thirteen cubes and no group: a table with range-skip nodes, but a single launch unless levels are asked for
+    ch12 = rt.SceneFile.from_file(scene_path("chapter_12")).build_world()
+    assert build(ch12) in (1, 2)
+    monkeypatch.setenv("RT_RENDER_LEVELS", "1")
+    assert build(ch12) == 3
     monkeypatch.setenv("RT_RENDER_LEVELS", "0")
     assert (build(ch11), build(ch14), build(large)) == (0, 2, 1)
     monkeypatch.setenv("RT_RENDER_LEVELS", "1")
