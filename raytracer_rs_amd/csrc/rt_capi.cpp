@@ -309,6 +309,9 @@ int rt_scene_create(const rt_world_desc *world, int device, rt_scene **out) {
     sc->uneven = sc->dev.max_nesting > 0;
     sc->by_levels = render_by_levels(sc->dev.max_nesting, sc->flat.n_groups);
     for (const RtSurface &s : sc->flat.surfaces) sc->uneven = sc->uneven || s.reflectivity != 0.0 || s.transparency != 0.0;
+    sc->dev.no_secondary = 1;
+    for (const RtSurface &s : sc->flat.surfaces)
+        if (s.reflectivity != 0.0 || s.transparency != 0.0) sc->dev.no_secondary = 0;
     *out = sc.release();
     return RT_OK;
 }

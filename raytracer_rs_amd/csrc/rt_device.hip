@@ -2134,6 +2134,64 @@ __global__ __launch_bounds__(256) void place_stripes_kernel(const T *__restrict_
 
 inline unsigned blocks_for(unsigned n) { return (n + 255u) / 256u; }
 
+// Camera::render for a world without groups in which nothing reflects or transmits (World::reflected_color and
+// refracted_color return black without tracing, world.rs:156-162, 175-181), or with a recursion budget of 0: a pixel
+// is its primary ray, one shading and one shadow ray.  No loop, no stack of pending rays: half the registers of
+// render_kernel, so twice the waves per SIMD -- and such frames are made of short waves whose time is latency (a
+// record fetch after the other), which is what more waves hide.  The same functions in the same order as one round
+// of radiance(): the same bits.
+#ifndef RT_PRIMARY_WAVES
+#define RT_PRIMARY_WAVES 6
+#endif
+#ifndef RT_PRIMARY_KERNEL
+#define RT_PRIMARY_KERNEL 1
+#endif
+__global__ __launch_bounds__(RENDER_BLOCK, RT_PRIMARY_WAVES) void primary_kernel(DeviceScene scene, RtCameraDev cam, RowMap rows, double *__restrict__ rgb) {
+    __shared__ double staging[192];
+    const unsigned lane = threadIdx.x & 63;
+    unsigned tile = blockIdx.x;
+    if (rows.tile_list) {
+        if (tile >= rows.n_tiles) return;
+        tile = ((const unsigned RT_CONSTANT_AS *)rows.tile_list)[TILE_HEADER + tile];
+    }
+    const unsigned tiles_x = (cam.hsize + 7) >> 3;
+    const unsigned x = (tile % tiles_x) * 8 + (lane & 7);
+    const unsigned r = (tile / tiles_x) * 8 + (lane >> 3);  // row in the packed output
+    const unsigned y = image_row(rows, r);
+    const bool valid = x < cam.hsize && r < rows.n_rows && y < rows.row_end;
+    SceneK S = scene_k<0, false>(scene, 0);
+    Ctr<false> ctr;
+    V3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+    if (valid) ray_for_pixel(cam, x, y, ro, rd);
+    V3 acc = mk(0.0, 0.0, 0.0);
+    const Closest<false> best = trace<0, false, false>(S, ro, rd, valid, (double)INFINITY, ctr);
+    const bool shade = valid && best.leaf >= 0 && S.light.has_light;  // else black: world.rs:124, world.rs:86-89
+    V3 acc_lit = acc, sro = ro, srd = rd;
+    double h_dist = 0.0;
+    bool own_shadow = false;
+    if (shade) {
+        HitShade h;
+        const V3 light_pos = mk(S.light.position[0], S.light.position[1], S.light.position[2]);
+        shade_hit<true, false, RT_OWN_SHADOW>(S.light, light_pos, S.surfaces + best.leaf, ro, rd, best.t, 1.0, 0, h, ctr);
+        acc_lit = acc + h.lit * 1.0;
+        acc = acc + h.shadowed * 1.0;
+        h_dist = h.light_distance;
+        sro = h.over;
+        srd = h.shadow_dir;
+        own_shadow = h.own_shadow;
+    }
+    if (__ballot(shade) != 0ull) {
+        const bool walk = shade && !own_shadow;
+        bool in_shadow = own_shadow;
+        if (__ballot(walk) != 0ull) {
+            const int start = __builtin_amdgcn_readlane(best.leaf, __builtin_ctzll(__ballot(walk)));
+            in_shadow = occluded<0, false, true>(S, sro, srd, walk, h_dist, ctr, start) || own_shadow;  // world.rs:145-148
+        }
+        if (shade && !in_shadow) acc = acc_lit;
+    }
+    store_tile(cam, rows, tile, lane, valid, x, r, y, acc, staging, rgb);
+}
+
 }  // namespace
 
 // The kernels exist in two builds: for scenes without groups (NEST = 0: every record a leaf, no group or range-skip
@@ -2194,6 +2252,8 @@ hipError_t launch_render(const DeviceScene &scene, const RtCameraDev &camera, co
     const unsigned block = RENDER_BLOCK;
     if (counters)
         launch_render_nest<true>(scene.max_nesting, grid, block, stream, scene, camera, rows, max_depth, rgb, counters);
+    else if (RT_PRIMARY_KERNEL && scene.max_nesting == 0 && (scene.no_secondary != 0 || max_depth == 0))
+        primary_kernel<<<grid, block, 0, stream>>>(scene, camera, rows, rgb);
     else
         launch_render_nest<false>(scene.max_nesting, grid, block, stream, scene, camera, rows, max_depth, rgb, nullptr);
     hipError_t launched = hipGetLastError();

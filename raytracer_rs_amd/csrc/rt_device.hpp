@@ -18,6 +18,7 @@ struct DeviceScene {
     int32_t max_nesting = 0;  // deepest nesting level of any node (0: no groups)
     int32_t any_order = 0;    // non-zero: some sibling list of the table is not in the reference's order
     int32_t cone_nodes = 0;   // non-zero: some range-skip node has cones below it (RT_SKIP_CONES)
+    int32_t no_secondary = 0; // non-zero: no surface of the world reflects or transmits: a pixel is its primary ray and one shadow ray
     uint32_t table_records = 0;  // records per node table, the inert trailing one included (n_nodes + 1)
     unsigned long long oct_tables = 0;  // byte k: which of the node tables (one after the other at `nodes`) suits rays of
                                         // direction octant k (bit a of k set: travelling towards -a); all zero: one table
