@@ -145,7 +145,7 @@ def committed_pmc(config: str) -> dict:
 
 def kernel_name(scene) -> str:
     info = scene.info()
-    return {0: "render_kernel<false, 0, false>", 2: "render_kernel<false, 2, true>",
+    return {0: "render_kernel<false, 0, false>", 2: "render_kernel<false, 2, true>", 4: "primary_kernel (one round: nothing in the world reflects or transmits)",
             3: "level_kernel (one launch per level of the ray trees, plus sums; scans and numbering for a view's first frame)"}.get(
                 info.kernel_build, "render_kernel<false, 1, true>")
 

@@ -163,7 +163,8 @@ typedef struct rt_scene_info {
                              3 = a world with groups, rendered level by level of its ray trees through queues in device
                              memory (rt_render_device_noalloc serves such a world only for views rendered before);
                              1 and 2 serve worlds with groups only when RT_RENDER_LEVELS=0 was in the environment
-                             when the scene was created */
+                             when the scene was created; 4 = a table of leaves only in which nothing reflects or
+                             transmits: a kernel of one round (primary ray, shading, shadow ray) */
 } rt_scene_info;
 
 /* struct Computations (rendering/intersections.rs:12-24); `object` is an index into rt_world_desc.objects. */

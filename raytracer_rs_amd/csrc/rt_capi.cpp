@@ -354,7 +354,7 @@ int rt_scene_get_info(const rt_scene *scene, rt_scene_info *out) {
     out->max_nesting = scene->flat.max_nesting;
     out->device_bytes = scene->device_bytes;
     out->device = scene->device;
-    out->kernel_build = scene->dev.max_nesting == 0 ? 0 : scene->by_levels ? 3 : (scene->dev.any_order != 0 && scene->dev.cone_nodes == 0) ? 2 : 1;
+    out->kernel_build = scene->dev.max_nesting == 0 ? (scene->dev.no_secondary ? 4 : 0) : scene->by_levels ? 3 : (scene->dev.any_order != 0 && scene->dev.cone_nodes == 0) ? 2 : 1;
     out->device_bytes += scene->levels.device_bytes();
     return RT_OK;
 }
